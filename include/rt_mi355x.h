@@ -1,0 +1,291 @@
+/*
+ * rt_mi355x.h — C ABI of the MI355X (gfx950) path-tracing core.
+ *
+ * This library replaces the OpenGL dispatch of the reference renderer
+ * (jaafer06/ray_tracing): the class RayTracingComputeShader
+ * (src/gpu_version/ray_tracing_compute_shader.h:9-67), the two compute
+ * dispatches of the frame loop (src/main.cpp:139-151) and the two shaders
+ * behind them (src/shaders/RayTracing.glsl, src/shaders/PixelConversion.glsl).
+ *
+ * Scene data crosses the boundary as raw bytes in the reference's own struct
+ * layouts, so a host that keeps using the reference's shape.h / camera.h
+ * structs can hand its std::vector<Shape>::data() straight in:
+ *
+ *   rt_material  32 B  = Material        (src/gpu_version/shape.h:5-12)
+ *   rt_shape    144 B  = Shape           (src/gpu_version/shape.h:44-54,
+ *                                         std430 twin RayTracing.glsl:86-97)
+ *   rt_triangle  64 B  = SimpleTriangle  (src/gpu_version/shape.h:81-109,
+ *                                         std430 twin RayTracing.glsl:10-16)
+ *   camera      21 f32 = Camera::data    (src/gpu_version/camera.h:115-117,
+ *                                         std430 twin RayTracing.glsl:28-36)
+ *
+ * Conventions: every entry point returns RT_OK (0) or a negative rt_status;
+ * nothing throws across the boundary; rt_last_error() gives a message for
+ * the last failure on that context.  A context is bound to one HIP device and
+ * must be driven by one host thread at a time.  All device work is queued on
+ * the context's stream (rt_set_stream); entry points that return data to host
+ * memory synchronise that stream before returning, the others do not.
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ types */
+
+/* Material: src/gpu_version/shape.h:5-12.  type: 0 Light, 1 Lambertian,
+ * 2 Metal, 100 Debug (shape.h:14-42); 3 Dielectric is an extension with no
+ * counterpart in the reference.  data[0] is what the reference's Metal ctor
+ * stores ("refraction", never read by its shader; the Dielectric extension
+ * reads it as the index of refraction); data[1] is the metal fuzz radius of
+ * the CPU tracer (src/cpu_version/scene.h:71,78), 0 = perfect mirror. */
+typedef struct rt_material {
+    float    color[3];
+    uint32_t type;
+    float    data[4];
+} rt_material;
+
+/* Shape: src/gpu_version/shape.h:44-54.  transformation is column-major;
+ * column 3 holds the translation, element [0][0] the radius (Circle,
+ * shape.h:56-62) or the cube side (Box, shape.h:64-70 as read by
+ * RayTracing.glsl:139).  type: 0 Circle, 1 Box. */
+typedef struct rt_shape {
+    float       transformation[16];
+    uint32_t    type;
+    float       data[11];
+    rt_material material;
+} rt_shape;
+
+/* SimpleTriangle: src/gpu_version/shape.h:81-109. */
+typedef struct rt_triangle {
+    float position[4];   /* first vertex, w unused               */
+    float a[3];          /* unit plane normal                    */
+    float beta;          /* a . position                         */
+    float m1[4];         /* dual basis of (v1, v2), w unused     */
+    float m2[4];
+} rt_triangle;
+
+#define RT_CAMERA_FLOATS 21u   /* src/gpu_version/camera.h:115 */
+
+enum rt_material_type { RT_MAT_LIGHT = 0, RT_MAT_LAMBERTIAN = 1, RT_MAT_METAL = 2,
+                        RT_MAT_DIELECTRIC = 3, RT_MAT_DEBUG = 100 };
+enum rt_shape_type    { RT_SHAPE_CIRCLE = 0, RT_SHAPE_BOX = 1 };
+
+/* Which of the reference's two tracers the context reproduces. */
+enum rt_semantics {
+    RT_SEM_CPU  = 0,  /* src/cpu_version: rayTracer.h:110-132, scene.h:39-255, utils.h:37-64 */
+    RT_SEM_GLSL = 1   /* src/shaders/RayTracing.glsl:206-308 + PixelConversion.glsl          */
+};
+
+/* Where inside its pixel a sample's camera ray starts. */
+enum rt_sample_mode {
+    RT_SAMPLE_JITTER      = 0, /* two uniform draws per sample (RayTracing.glsl:296)            */
+    RT_SAMPLE_GRID        = 1, /* regular N x N grid, spp = N*N, step worldStep/(N+1)           */
+    RT_SAMPLE_GRID_COMPAT = 2  /* rayTracer.h:92-101 as written: the x offset accumulates       */
+};
+
+enum rt_flags {
+    /* scene.h:78 leaves the fuzzed metal direction un-normalised although
+     * Sphere::hit assumes a unit direction; by default it is normalised.
+     * With this flag it is left as the reference leaves it. */
+    RT_FLAG_METAL_UNNORMALIZED = 1u << 0
+};
+
+enum rt_status {
+    RT_OK                 =  0,
+    RT_ERR_INVALID_ARG    = -1,
+    RT_ERR_NO_DEVICE      = -2,
+    RT_ERR_HIP            = -3,
+    RT_ERR_OUT_OF_MEMORY  = -4,
+    RT_ERR_STATE          = -5,
+    RT_ERR_IO             = -6
+};
+
+typedef struct rt_config {
+    uint32_t struct_size;      /* = sizeof(rt_config)                            */
+    int32_t  device;           /* HIP device ordinal                             */
+    uint32_t semantics;        /* enum rt_semantics                              */
+    uint32_t sample_mode;      /* enum rt_sample_mode                            */
+    uint32_t flags;            /* enum rt_flags                                  */
+    float    triangle_albedo[3]; /* RayTracing.glsl:275 hard-codes (1,0,0)       */
+} rt_config;
+
+/* Work counters of the last rt_render call that asked for them. */
+typedef struct rt_stats {
+    uint64_t samples;          /* camera paths started                           */
+    uint64_t segments;         /* ray segments traced (closest-hit queries)      */
+    uint64_t diffuse;          /* Lambertian / triangle scatter events           */
+    uint64_t specular;         /* metal + dielectric scatter events              */
+    uint64_t terminal;         /* paths ended by light, miss, absorb or depth    */
+    uint64_t shape_tests;      /* ray-sphere + ray-box tests                     */
+    uint64_t sphere_tests;
+    uint64_t box_tests;
+    uint64_t triangle_tests;
+} rt_stats;
+
+typedef struct rt_ctx rt_ctx;
+
+/* ------------------------------------------------------- context lifetime */
+
+/* Replaces RayTracingComputeShader::RayTracingComputeShader
+ * (ray_tracing_compute_shader.h:12-32: creates the camera, shape and
+ * triangle buffers) and LoadShaders() (src/gpu_version/loadShader.h:61-103;
+ * the HIP kernels are linked into this library). */
+int  rt_create(rt_ctx** out, const rt_config* cfg);
+void rt_destroy(rt_ctx* ctx);
+
+/* Text of the last error on ctx (or of the last failed rt_create if ctx is
+ * NULL).  The reference has no error convention (loadShader.h:27-31 prints
+ * and continues); this replaces it. */
+const char* rt_last_error(const rt_ctx* ctx);
+
+/* Queue all later work of ctx on this hipStream_t (NULL = the default
+ * stream).  No counterpart in the reference (one GL context, one queue). */
+int rt_set_stream(rt_ctx* ctx, void* hip_stream);
+
+/* ------------------------------------------------------------ scene upload */
+
+/* Replace RayTracingComputeShader::updateShapeBuffer
+ * (ray_tracing_compute_shader.h:44-57): glBufferData of shapes.data() with
+ * sizeof(Shape) stride + glUniform1ui(shapeCount), and the same for the
+ * SimpleTriangle vector + triangleCount.  The caller keeps its arrays; the
+ * library copies and repacks them before returning.  n = 0 clears. */
+int rt_upload_shapes(rt_ctx* ctx, const rt_shape* shapes, uint32_t n);
+int rt_upload_triangles(rt_ctx* ctx, const rt_triangle* triangles, uint32_t n);
+
+/* Replaces RayTracingComputeShader::updateCameraBuffer
+ * (ray_tracing_compute_shader.h:34-37): 21 floats, Camera::data. */
+int rt_set_camera(rt_ctx* ctx, const float data[RT_CAMERA_FLOATS]);
+
+/* ----------------------------------------------------------------- render */
+
+/* Restrict rendering to the image rows y with (y / band_rows) % shard_count
+ * == shard_index; the other rows of the accumulator are left untouched.
+ * (0, 1, any) renders every row.  No counterpart in the reference (single
+ * GPU); it is how one frame is split over the GPUs of a node. */
+int rt_set_row_shard(rt_ctx* ctx, uint32_t shard_index, uint32_t shard_count,
+                     uint32_t band_rows);
+
+/* Use caller-owned device memory (width*height*4 32-bit words, 16-byte
+ * aligned) as the accumulator instead of the context's own, so that a
+ * collective can run on it directly.  NULL goes back to the internal one.
+ * The buffer is used as it is: zero it (or call rt_reset_accum) to start. */
+int rt_bind_accum(rt_ctx* ctx, void* device_words, uint32_t width, uint32_t height);
+
+/* Replaces glUniform1f(time) + RayTracingComputeShader::compute(width,
+ * height, 1) (src/main.cpp:139-145; ray_tracing_compute_shader.h:39-42) and,
+ * for RT_SEM_CPU, Camera::render() of the CPU tracer
+ * (src/cpu_version/rayTracer.h:71-87).  Traces samples [first_sample,
+ * first_sample + spp) of every pixel and adds them to the accumulator.
+ * max_depth = most ray segments per path (RayTracing.glsl:263,300 uses 10;
+ * rayTracer.h:78,113 traces steps + 1 = 11).  seed replaces the wall-clock
+ * `time` uniform.  For the grid sample modes grid_n * grid_n samples make one
+ * pixel; pass 0 to derive grid_n from first_sample + spp (must be a square).
+ * Asynchronous on the context's stream. */
+int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp,
+              uint32_t max_depth, uint64_t seed, uint32_t first_sample,
+              uint32_t grid_n);
+
+/* The same render, and also fills `out` with the work counters (synchronises
+ * the stream).  The image produced is bit-identical to rt_render's. */
+int rt_render_stats(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp,
+                    uint32_t max_depth, uint64_t seed, uint32_t first_sample,
+                    uint32_t grid_n, rt_stats* out);
+
+/* Number of samples per pixel added to the accumulator since the last reset. */
+int rt_accum_samples(const rt_ctx* ctx, uint32_t* out);
+
+/* main.cpp:179,194 (number_of_samples = 1): drop everything accumulated. */
+int rt_reset_accum(rt_ctx* ctx);
+
+/* ---------------------------------------------------------------- resolve */
+
+/* Replaces the converter dispatch (src/main.cpp:147-149,
+ * PixelConversion.glsl:12-20) for one frame, and rayTracer.h:105 for
+ * RT_SEM_CPU: out = accumulated / samples as width*height RGBA float32
+ * (alpha 1).  gamma_sqrt applies rayTracer.h:105's cwiseSqrt; flip_rows
+ * stores image row y at row height-1-y, the orientation both reference
+ * tracers write (rayTracer.h:78, RayTracing.glsl:303).  Synchronises. */
+int rt_resolve(rt_ctx* ctx, float* rgba_host, int gamma_sqrt, int flip_rows);
+
+/* The same into device memory, asynchronous on the context's stream. */
+int rt_resolve_device(rt_ctx* ctx, float* rgba_device, int gamma_sqrt, int flip_rows);
+
+/* The progressive form of the converter (PixelConversion.glsl:12-28 with
+ * src/main.cpp:147-151): folds the accumulator into the context's running
+ * mean image with weight 1/n_samples, then zeroes the accumulator.
+ * n_samples = 1 restarts the mean (main.cpp:179,194). */
+int rt_convert(rt_ctx* ctx, uint32_t n_samples);
+
+/* Copy the running-mean image (the RGBA32F texture of main.cpp:72-79) to
+ * host memory, in the reference's row order.  Synchronises. */
+int rt_read_image(rt_ctx* ctx, float* rgba_host);
+
+/* ------------------------------------------------------------------ debug */
+
+/* For exactness checks (the reference's only aid of this kind is
+ * DebugMaterial, shape.h:37-42): re-traces sample `sample` of every pixel
+ * without touching the accumulator and writes, per pixel and bounce b <
+ * max_depth, the index of the primitive hit (shape index, or n_shapes +
+ * triangle index; -1 = miss, -2 = path had already ended) and its material
+ * type (0xFFFFFFFF where there is none).  Arrays are host memory of
+ * width*height*max_depth entries, pixel-major, rows unflipped. */
+int rt_trace_debug(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t max_depth,
+                   uint64_t seed, uint32_t sample, uint32_t grid_n,
+                   int32_t* hit_index_host, uint32_t* material_id_host);
+
+/* ------------------------------------------- host-side scene construction */
+/* Plain-C forms of the reference's host constructors, so that a host without
+ * the reference's Eigen-based headers builds byte-identical structs. */
+
+/* Camera::Camera (src/gpu_version/camera.h:14-28); position (1,1,6) there,
+ * (1,0,6) in the CPU tracer (rayTracer.h:37). */
+void rt_camera_init(float data[RT_CAMERA_FLOATS], uint32_t width, uint32_t height,
+                    float focal_length, const float position[3]);
+/* Camera::rotate / Camera::move (camera.h:85-113).  direction: 0 forward,
+ * 1 backward, 2 right, 3 left. */
+void rt_camera_rotate(float data[RT_CAMERA_FLOATS], uint32_t width, uint32_t height,
+                      float focal_length, float horizontal, float vertical);
+void rt_camera_move(float data[RT_CAMERA_FLOATS], uint32_t width, uint32_t height,
+                    float focal_length, int direction);
+
+/* Circle / Box constructors (shape.h:56-70). */
+void rt_make_circle(rt_shape* out, const float translation[3], float radius,
+                    const rt_material* material);
+void rt_make_box(rt_shape* out, const float translation[3], const float sides[3],
+                 const rt_material* material);
+/* SimpleTriangle::SimpleTriangle (shape.h:83-102). */
+void rt_make_triangle(rt_triangle* out, const float p1[3], const float p2[3],
+                      const float p3[3]);
+
+/* SimpleMesh (src/SimpleMesh.h): loadMesh :145-215, normalize :60-68,
+ * resize :79-85, transform :122-126, and the mesh -> SimpleTriangle loop of
+ * src/main.cpp:113-122. */
+typedef struct rt_mesh rt_mesh;
+int      rt_mesh_load(rt_mesh** out, const char* off_path);
+void     rt_mesh_free(rt_mesh* mesh);
+uint32_t rt_mesh_vertex_count(const rt_mesh* mesh);
+uint32_t rt_mesh_triangle_count(const rt_mesh* mesh);
+void     rt_mesh_normalize(rt_mesh* mesh);
+void     rt_mesh_resize(rt_mesh* mesh);
+void     rt_mesh_transform(rt_mesh* mesh, const float rotation_rowmajor[9],
+                           const float translation[3]);
+/* positions: n*4 floats (xyzw); colors: n*4 floats; indices: n*3 uint32. */
+void     rt_mesh_copy_vertices(const rt_mesh* mesh, float* positions_xyzw, float* colors_rgba);
+void     rt_mesh_copy_indices(const rt_mesh* mesh, uint32_t* indices);
+/* Writes rt_mesh_triangle_count() SimpleTriangles. */
+void     rt_mesh_to_triangles(const rt_mesh* mesh, rt_triangle* out);
+
+/* Library / device facts for reports. */
+int rt_device_info(int device, char* name, size_t name_len, int* compute_units,
+                   int* clock_mhz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */

@@ -1,0 +1,768 @@
+/*
+ * rt_oracle.c — CPU restatement of the reference path tracer (TEST ORACLE).
+ *
+ * Test infrastructure only; see rt_oracle.h.  PARITY UNPINNED BY THE
+ * REFERENCE (it holds no golden vectors and cannot be built or seeded here).
+ *
+ * Written as scalar C that keeps the reference's structure (a scene loop, a
+ * scatter per material, a recursive ray_color for the CPU tracer).  Build with
+ * -ffp-contract=off: every fused multiply-add in the arithmetic below is an
+ * explicit fmaf(), everything else is a separately rounded IEEE-754 binary32
+ * operation, so a second implementation can match it bit for bit.  No libm
+ * function other than sqrtf/fmaf/fabsf (all exactly rounded) feeds geometry;
+ * the ORC_UNIT_GAUSS sampler, which uses logf/cosf/sinf, exists only for a
+ * statistical cross-check.
+ *
+ * Arithmetic conventions used throughout:
+ *   dot(a,b)      = fmaf(a.z,b.z, fmaf(a.y,b.y, a.x*b.x))
+ *   madd(t,d,o)   = fmaf(t,d,o) per component               (o + t*d)
+ *   normalize(v)  = v * (1.0f / sqrtf(dot(v,v)))
+ */
+#include "rt_oracle.h"
+
+#include <ctype.h>
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct { float x, y, z; } v3;
+
+static inline v3 V(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vmul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 vscale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline float dot(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline v3 madd(float t, v3 d, v3 o) { return V(fmaf(t, d.x, o.x), fmaf(t, d.y, o.y), fmaf(t, d.z, o.z)); }
+static inline v3 normalize(v3 v) { float inv = 1.0f / sqrtf(dot(v, v)); return vscale(v, inv); }
+static inline v3 cross(v3 a, v3 b)
+{
+    return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+/* GLSL sign(): -1, 0 or 1 (NaN -> 0). */
+static inline float fsign(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+/* GLSL max(x,y) = (x < y) ? y : x. */
+static inline float gmax(float x, float y) { return (x < y) ? y : x; }
+
+/* --------------------------------------------------------------------- RNG
+ * The reference's streams cannot be reproduced (utils.h:8-9: mt19937 seeded
+ * from random_device and shared by all threads; RayTracing.glsl:8-9,44-51:
+ * a sin-hash of wall-clock time).  What is kept is their structure: one
+ * stream per (seed, pixel, sample), indexed by draw number.  draw i of a path
+ * is hash32(key + i * 0x9E3779B9) with key = f(seed, pixel, sample). */
+uint32_t orc_hash32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+static uint32_t seed_key(uint64_t seed)
+{
+    return orc_hash32((uint32_t)seed ^ orc_hash32((uint32_t)(seed >> 32) ^ 0x85ebca6bu));
+}
+
+uint32_t orc_path_key(uint64_t seed, uint32_t pixel_index, uint32_t sample)
+{
+    uint32_t h1 = orc_hash32(seed_key(seed) ^ pixel_index);
+    return orc_hash32(h1 ^ sample);
+}
+
+/* Uniform in [0,1) with 24 bits, like random() of RayTracing.glsl:44-51. */
+float orc_draw(uint32_t key, uint32_t index)
+{
+    uint32_t h = orc_hash32(key + index * 0x9e3779b9u);
+    return (float)(h >> 8) * 0x1p-24f;
+}
+
+/* Draw numbering inside one path: 0,1 = sub-pixel jitter (RayTracing.glsl:296,
+ * first draw goes with `right`, second with `up`); bounce b owns draws
+ * 2+4b .. 5+4b. */
+#define DRAW_JITTER 0u
+#define DRAW_BOUNCE(b) (2u + 4u * (uint32_t)(b))
+
+/* cos(2 pi u), sin(2 pi u) for u in [0,1) from fmaf/mul only, so that it is
+ * the same function on every machine.  Stands in for the cos/sin of
+ * RayTracing.glsl:69-70 and for the angular part of utils.h:45. */
+void orc_sincos2pi(float u, float* c_out, float* s_out)
+{
+    float t = u * 4.0f;                 /* exact */
+    int q = (int)t;                     /* quadrant 0..3 */
+    float f = t - (float)q;             /* exact, in [0,1) */
+    float x = f * 0x1.921fb6p+0f;       /* f * pi/2 */
+    float x2 = x * x;
+    float ps = -0x1.ae6456p-26f;
+    ps = fmaf(ps, x2, 0x1.71de3ap-19f);
+    ps = fmaf(ps, x2, -0x1.a01a02p-13f);
+    ps = fmaf(ps, x2, 0x1.111112p-7f);
+    ps = fmaf(ps, x2, -0x1.555556p-3f);
+    ps = fmaf(ps, x2, 1.0f);
+    float s = x * ps;
+    float pc = 0x1.1eed8ep-29f;
+    pc = fmaf(pc, x2, -0x1.27e4fcp-22f);
+    pc = fmaf(pc, x2, 0x1.a01a02p-16f);
+    pc = fmaf(pc, x2, -0x1.6c16c2p-10f);
+    pc = fmaf(pc, x2, 0x1.555556p-5f);
+    pc = fmaf(pc, x2, -0.5f);
+    float c = fmaf(pc, x2, 1.0f);
+    switch (q & 3) {
+    case 0: *c_out = c;  *s_out = s;  break;
+    case 1: *c_out = -s; *s_out = c;  break;
+    case 2: *c_out = -c; *s_out = -s; break;
+    default: *c_out = s; *s_out = -c; break;
+    }
+}
+
+/* randomUnitVector() of utils.h:37-46: a normalised vector of three normal
+ * deviates, i.e. a point uniform on the unit sphere.  Sampled directly:
+ * z uniform in (-1,1], azimuth uniform. */
+void orc_unit_vector(float u1, float u2, float out[3])
+{
+    float z = fmaf(-2.0f, u1, 1.0f);
+    float r = sqrtf(fmaf(-z, z, 1.0f));
+    float c, s;
+    orc_sincos2pi(u2, &c, &s);
+    out[0] = r * c; out[1] = r * s; out[2] = z;
+}
+
+/* utils.h:45 literally: three N(0,1) deviates, normalised.  The deviates come
+ * from Box-Muller on four draws, the construction the reference itself writes
+ * in RayTracing.glsl:53-62.  libm; statistical cross-check only. */
+static v3 unit_vector_gauss(uint32_t key, uint32_t base)
+{
+    float u1 = orc_draw(key, base), u2 = orc_draw(key, base + 1);
+    float u3 = orc_draw(key, base + 2), u4 = orc_draw(key, base + 3);
+    if (u1 < 0x1p-24f) u1 = 0x1p-24f;
+    if (u3 < 0x1p-24f) u3 = 0x1p-24f;
+    float r1 = sqrtf(-2.0f * logf(u1)), r2 = sqrtf(-2.0f * logf(u3));
+    float a1 = 6.283185307179586f * u2, a2 = 6.283185307179586f * u4;
+    v3 n = V(r1 * cosf(a1), r1 * sinf(a1), r2 * cosf(a2));
+    return normalize(n);
+}
+
+/* randomOnHalfUnitShere, RayTracing.glsl:64-80. */
+void orc_hemisphere_glsl(const float nn[3], float u1, float u2, float out[3])
+{
+    v3 n = V(nn[0], nn[1], nn[2]);
+    float c, s;
+    orc_sincos2pi(u1, &c, &s);                         /* angle = random()*2*pi        :66 */
+    float r = u2;                                      /* r = random()                 :67 */
+    float dist = sqrtf(fmaf(-r, r, 1.0f));             /* sqrt(1 - r*r)                :68 */
+    float x = c * dist, y = s * dist;                  /*                              :69-70 */
+    v3 b1 = V(-n.y, n.x, 0.0f);                        /*                              :71 */
+    float len_xy = sqrtf(fmaf(b1.y, b1.y, b1.x * b1.x));
+    if (len_xy < 0.01f) b1 = normalize(V(0.0f, -n.z, n.y));   /*                      :72-73 */
+    else b1 = normalize(b1);                           /*                              :75 */
+    v3 b2 = cross(n, b1);                              /*                              :77 */
+    /* b1*x + b2*y + normal*r                                                          :78 */
+    out[0] = fmaf(n.x, r, fmaf(b2.x, y, b1.x * x));
+    out[1] = fmaf(n.y, r, fmaf(b2.y, y, b1.y * x));
+    out[2] = fmaf(n.z, r, fmaf(b2.z, y, b1.z * x));
+}
+
+/* ------------------------------------------------------------ intersection */
+
+/* Sphere::hit, scene.h:115-128 == hitSphere, RayTracing.glsl:118-132.
+ * Near root only; needs a unit direction.  Returns +inf when there is no
+ * real root. */
+float orc_hit_sphere(const float cc[3], float radius, const float oo[3], const float dd[3])
+{
+    v3 oc = vsub(V(oo[0], oo[1], oo[2]), V(cc[0], cc[1], cc[2]));   /* scene.h:116 */
+    v3 d = V(dd[0], dd[1], dd[2]);
+    float b = dot(oc, d);                                            /* :117 */
+    float c = dot(oc, oc) - radius * radius;                         /* :118 */
+    float disc = fmaf(b, b, -c);                                     /* :119 */
+    if (disc < 0.0f) return INFINITY;                                /* :120 */
+    return -b - sqrtf(disc);                                         /* :123 */
+}
+
+/* hitBox, RayTracing.glsl:138-156: a cube of side transformation[0][0]. */
+float orc_hit_box(const float cc[3], float scale, const float oo[3], const float dd[3])
+{
+    float inv = 1.0f / scale;                                        /* (1/scale)   :141 */
+    float o[3], d[3], sg[3], t[3];
+    for (int k = 0; k < 3; ++k) {
+        o[k] = inv * (oo[k] - cc[k]);                                /* :141 */
+        d[k] = inv * dd[k];                                          /* :142 */
+        sg[k] = fsign(o[k]);                                         /* :144 */
+        t[k] = (0.5f - o[k] * sg[k]) / (sg[k] * d[k]);               /* :145 */
+    }
+    float best = INFINITY;                                           /* :146 */
+    for (int k = 0; k < 3; ++k) {                                    /* :147 */
+        float px = fabsf(fmaf(d[0], t[k], o[0]));                    /* :148-149 */
+        float py = fabsf(fmaf(d[1], t[k], o[1]));
+        float pz = fabsf(fmaf(d[2], t[k], o[2]));
+        float inf_norm = gmax(px, gmax(py, pz));                     /* :150 */
+        if (inf_norm < 0.5001f && inf_norm > 0.4999f && best > t[k]) /* :151 */
+            best = t[k];
+    }
+    return best;
+}
+
+/* boxNormalAt, RayTracing.glsl:158-163. */
+void orc_box_normal(const float cc[3], float scale, const float pp[3], float nn[3])
+{
+    float q[3];
+    for (int k = 0; k < 3; ++k) {
+        float p = (pp[k] - cc[k]) / scale;                           /* :161 */
+        float st = (fabsf(p) < 0.499f) ? 0.0f : 1.0f;                /* step(0.499,|p|) :162 */
+        q[k] = st * fsign(p);
+    }
+    v3 n = normalize(V(q[0], q[1], q[2]));
+    nn[0] = n.x; nn[1] = n.y; nn[2] = n.z;
+}
+
+/* hitTriangle, RayTracing.glsl:179-194. */
+float orc_hit_triangle(const orc_triangle* tr, const float oo[3], const float dd[3])
+{
+    v3 a = V(tr->a[0], tr->a[1], tr->a[2]);
+    v3 o = V(oo[0], oo[1], oo[2]), d = V(dd[0], dd[1], dd[2]);
+    float k = (tr->beta - dot(a, o)) / dot(a, d);                    /* :181 */
+    if (k < 0.0f) return INFINITY;                                   /* :182-184 */
+    v3 q = vsub(madd(k, d, o), V(tr->position[0], tr->position[1], tr->position[2])); /* :186 */
+    float x = dot(q, V(tr->m1[0], tr->m1[1], tr->m1[2]));            /* :187 */
+    float y = dot(q, V(tr->m2[0], tr->m2[1], tr->m2[2]));            /* :188 */
+    if (x > 0.0f && y > 0.0f && x + y < 1.0f) return k;              /* :190-192 */
+    return INFINITY;
+}
+
+/* ------------------------------------------------------------------ scene */
+
+typedef struct {
+    const orc_shape* shapes; uint32_t n_shapes;
+    const orc_triangle* tris; uint32_t n_tris;
+    const float* cam;
+    const orc_params* p;
+    uint32_t seed_k;
+    orc_stats st;                 /* per-thread */
+    int32_t* trace_hit; uint32_t* trace_mat;   /* per-path slices or NULL */
+} tracer;
+
+typedef struct { v3 o, d; } ray;
+
+static inline v3 shape_center(const orc_shape* s) { return V(s->m[12], s->m[13], s->m[14]); }
+
+static float hit_shape(tracer* T, const orc_shape* s, const ray* r)
+{
+    float c[3] = { s->m[12], s->m[13], s->m[14] };
+    float o[3] = { r->o.x, r->o.y, r->o.z }, d[3] = { r->d.x, r->d.y, r->d.z };
+    if (s->type == 0) { T->st.sphere_tests++; return orc_hit_sphere(c, s->m[0], o, d); }
+    if (s->type == 1) { T->st.box_tests++;    return orc_hit_box(c, s->m[0], o, d); }
+    return -1.0f;                                                     /* RayTracing.glsl:176 */
+}
+
+/* The acceptance window of a hit distance.  CPU: scene.h:237 with the
+ * arguments of rayTracer.h:117 — `t_min < temp.t` compares the double 0.001
+ * with a widened float, which holds exactly when t >= 0.001f.  GLSL:
+ * RayTracing.glsl:212,226. */
+static inline int in_window(const orc_params* p, float t)
+{
+    if (p->semantics == ORC_SEM_CPU) return t >= 0.001f && t < FLT_MAX;
+    return t < 1000.0f && t > 0.0001f;
+}
+
+/* Scene::hit (scene.h:232-255) / getClosestShapeIndex + getClosestTriangleIndex
+ * (RayTracing.glsl:206-231): linear scan, strict <, first index wins ties;
+ * a triangle replaces a shape only when strictly closer (RayTracing.glsl:271). */
+static int closest_hit(tracer* T, const ray* r, float* t_out)
+{
+    float best = INFINITY; int index = -1;
+    for (uint32_t i = 0; i < T->n_shapes; ++i) {
+        float t = hit_shape(T, &T->shapes[i], r);
+        T->st.shape_tests++;
+        if (in_window(T->p, t) && t < best) { best = t; index = (int)i; }
+    }
+    float best_tri = INFINITY; int index_tri = -1;
+    float o[3] = { r->o.x, r->o.y, r->o.z }, d[3] = { r->d.x, r->d.y, r->d.z };
+    for (uint32_t i = 0; i < T->n_tris; ++i) {
+        float t = orc_hit_triangle(&T->tris[i], o, d);
+        T->st.triangle_tests++;
+        if (in_window(T->p, t) && t < best_tri) { best_tri = t; index_tri = (int)i; }
+    }
+    if (index < 0 && index_tri < 0) return -1;                        /* RayTracing.glsl:267 */
+    if (best_tri < best) { *t_out = best_tri; return (int)T->n_shapes + index_tri; }  /* :271 */
+    *t_out = best;
+    return index;
+}
+
+static v3 shape_normal(const orc_shape* s, v3 p)
+{
+    if (s->type == 0) return normalize(vsub(p, shape_center(s)));      /* scene.h:130-132, glsl:134-136 */
+    if (s->type == 1) {
+        float c[3] = { s->m[12], s->m[13], s->m[14] }, pp[3] = { p.x, p.y, p.z }, n[3];
+        orc_box_normal(c, s->m[0], pp, n);
+        return V(n[0], n[1], n[2]);
+    }
+    return V(1.0f, 1.0f, 1.0f);                                       /* glsl:203 */
+}
+
+static v3 unit_vector(tracer* T, uint32_t key, uint32_t base)
+{
+    if (T->p->unit_sampler == ORC_UNIT_GAUSS) return unit_vector_gauss(key, base);
+    float u[3];
+    orc_unit_vector(orc_draw(key, base), orc_draw(key, base + 1), u);
+    return V(u[0], u[1], u[2]);
+}
+
+/* Outcome of the surface interaction at one hit. */
+enum { EV_SCATTER = 0, EV_EMIT = 1 };
+
+/* One hit under the CPU tracer's rules: Material::scatter / emit,
+ * scene.h:39-109.  On EV_SCATTER `att` is the attenuation and *r the new ray;
+ * on EV_EMIT `att` is what the path returns at this hit. */
+static int interact_cpu(tracer* T, int index, float t, ray* r, uint32_t key, int bounce, v3* att, uint32_t* mat_id)
+{
+    v3 p = madd(t, r->d, r->o);                                        /* Ray::at, scene.h:21-23 */
+    v3 n; v3 albedo; uint32_t type; float fuzz = 0.0f;
+    if (index >= (int)T->n_shapes) {
+        const orc_triangle* tr = &T->tris[index - (int)T->n_shapes];
+        v3 a = V(tr->a[0], tr->a[1], tr->a[2]);
+        n = vscale(a, fsign(-dot(r->d, a)));                           /* glsl:165-167 */
+        albedo = V(T->p->triangle_albedo[0], T->p->triangle_albedo[1], T->p->triangle_albedo[2]);
+        type = 1;
+    } else {
+        const orc_shape* s = &T->shapes[index];
+        n = shape_normal(s, p);
+        albedo = V(s->mat.color[0], s->mat.color[1], s->mat.color[2]);
+        type = s->mat.type; fuzz = s->mat.data[1];
+    }
+    *mat_id = type;
+    if (type == 1) {                                                   /* Lambertian::scatter, scene.h:51-58 */
+        v3 u = unit_vector(T, key, DRAW_BOUNCE(bounce));
+        v3 dir = madd(1.0001f, n, u);                                  /* utils.h:48-50 */
+        r->o = p; r->d = normalize(dir);                               /* Ray ctor, scene.h:14-16 */
+        *att = vscale(albedo, 0.6f);                                   /* scene.h:56 */
+        T->st.diffuse++;
+        return EV_SCATTER;
+    }
+    if (type == 2) {                                                   /* Metal::scatter, scene.h:73-81 */
+        float k = 2.0f * dot(n, r->d);                                 /* utils.h:62-64 */
+        v3 dir = madd(-k, n, r->d);
+        if (fuzz != 0.0f) dir = madd(fuzz, unit_vector(T, key, DRAW_BOUNCE(bounce)), dir);  /* scene.h:78 */
+        T->st.specular++;
+        if (!(dot(dir, n) > 0.0f)) { *att = V(0, 0, 0); return EV_EMIT; }  /* scene.h:80,83-85 */
+        r->o = p;
+        r->d = (T->p->flags & ORC_FLAG_METAL_UNNORMALIZED) ? dir : normalize(dir);
+        *att = albedo;                                                 /* scene.h:79 */
+        return EV_SCATTER;
+    }
+    if (type == 0) { *att = albedo; return EV_EMIT; }                  /* LightSource, scene.h:97-105 */
+    if (type == 100) { *att = n; return EV_EMIT; }                     /* DebugMaterial, glsl:248-252 */
+    *att = V(0, 0, 0);
+    return EV_EMIT;
+}
+
+/* ray_color, rayTracer.h:110-132, as written: recursive; the products are
+ * formed on the way back out. */
+static v3 ray_color_cpu_recursive(tracer* T, ray r, int depth, uint32_t key, int bounce)
+{
+    if (depth < 0) { T->st.terminal++; return V(0, 0, 0); }            /* :113-115 */
+    float t; T->st.segments++;
+    int index = closest_hit(T, &r, &t);                                /* :117 */
+    if (T->trace_hit) T->trace_hit[bounce] = index;
+    if (index < 0) { T->st.terminal++; return V(0, 0, 0); }            /* :131 */
+    v3 att; uint32_t mat;
+    int ev = interact_cpu(T, index, t, &r, key, bounce, &att, &mat);
+    if (T->trace_mat) T->trace_mat[bounce] = mat;
+    if (ev == EV_SCATTER)
+        return vmul(att, ray_color_cpu_recursive(T, r, depth - 1, key, bounce + 1)); /* :121 */
+    T->st.terminal++;
+    return att;                                                        /* :124 */
+}
+
+/* The same paths with the products formed camera-outwards. */
+static v3 ray_color_cpu_forward(tracer* T, ray r, int max_depth, uint32_t key)
+{
+    v3 thr = V(1, 1, 1);
+    for (int bounce = 0; bounce < max_depth; ++bounce) {
+        float t; T->st.segments++;
+        int index = closest_hit(T, &r, &t);
+        if (T->trace_hit) T->trace_hit[bounce] = index;
+        if (index < 0) { T->st.terminal++; return V(0, 0, 0); }
+        v3 att; uint32_t mat;
+        int ev = interact_cpu(T, index, t, &r, key, bounce, &att, &mat);
+        if (T->trace_mat) T->trace_mat[bounce] = mat;
+        if (ev == EV_EMIT) {
+            T->st.terminal++;
+            return vmul(thr, att);
+        }
+        thr = vmul(thr, att);
+    }
+    T->st.terminal++;
+    return V(0, 0, 0);
+}
+
+/* ray_color + scatter, RayTracing.glsl:233-288. */
+static v3 ray_color_glsl(tracer* T, ray r, int max_depth, uint32_t key)
+{
+    v3 result = V(1, 1, 1);                                            /* :258 */
+    for (int bounce = 0; bounce < max_depth; ++bounce) {               /* :263 */
+        float t; T->st.segments++;
+        int index = closest_hit(T, &r, &t);                            /* :264-265 */
+        if (T->trace_hit) T->trace_hit[bounce] = index;
+        if (index < 0) { T->st.terminal++; return V(0, 0, 0); }        /* :267-269 */
+        float u1 = orc_draw(key, DRAW_BOUNCE(bounce)), u2 = orc_draw(key, DRAW_BOUNCE(bounce) + 1);
+        if (index >= (int)T->n_shapes) {                               /* :271-277 */
+            const orc_triangle* tr = &T->tris[index - (int)T->n_shapes];
+            v3 a = V(tr->a[0], tr->a[1], tr->a[2]);
+            v3 n = vscale(a, fsign(-dot(r.d, a)));                     /* :272 */
+            r.o = madd(t, r.d, r.o);                                   /* :273 */
+            float nn[3] = { n.x, n.y, n.z }, out[3];
+            orc_hemisphere_glsl(nn, u1, u2, out);                      /* :274 */
+            r.d = V(out[0], out[1], out[2]);
+            result = vmul(result, V(T->p->triangle_albedo[0], T->p->triangle_albedo[1], T->p->triangle_albedo[2])); /* :275 */
+            if (T->trace_mat) T->trace_mat[bounce] = 1;
+            T->st.diffuse++;
+            continue;
+        }
+        const orc_shape* s = &T->shapes[index];
+        v3 color = V(s->mat.color[0], s->mat.color[1], s->mat.color[2]);
+        uint32_t type = s->mat.type;
+        if (T->trace_mat) T->trace_mat[bounce] = type;
+        if (type == 0) { T->st.terminal++; return vmul(result, color); }  /* :278-280 (and :235-237) */
+        if (type == 1) {                                               /* :238-242 */
+            r.o = madd(t, r.d, r.o);
+            v3 n = shape_normal(s, r.o);
+            float nn[3] = { n.x, n.y, n.z }, out[3];
+            orc_hemisphere_glsl(nn, u1, u2, out);
+            r.d = V(out[0], out[1], out[2]);
+            result = vmul(result, color);
+            T->st.diffuse++;
+            continue;
+        }
+        if (type == 2) {                                               /* :243-247, reflect :82-84 */
+            r.o = madd(t, r.d, r.o);
+            v3 n = shape_normal(s, r.o);
+            float k = 2.0f * dot(r.d, n);
+            r.d = normalize(madd(-k, n, r.d));
+            result = vmul(result, color);
+            T->st.specular++;
+            continue;
+        }
+        T->st.terminal++;
+        if (type == 100) {                                             /* :248-252 */
+            r.o = madd(t, r.d, r.o);
+            return shape_normal(s, r.o);
+        }
+        return result;                                                 /* :253, :282-284 */
+    }
+    T->st.terminal++;
+    return V(0, 0, 0);                                                 /* :287 */
+}
+
+/* -------------------------------------------------------------- camera ray */
+
+static inline v3 cam3(const float* cam, int off) { return V(cam[off], cam[off + 1], cam[off + 2]); }
+
+/* rayTracer.h:77 / RayTracing.glsl:293: upperLeft + step*gx*right - step*gy*up. */
+static v3 pixel_corner(const float* cam, uint32_t gx, uint32_t gy)
+{
+    float step = cam[19];
+    v3 ul = cam3(cam, 8), up = cam3(cam, 12), right = cam3(cam, 16);
+    float sx = step * (float)gx, sy = step * (float)gy;
+    return madd(-sy, up, madd(sx, right, ul));
+}
+
+static uint32_t isqrt_u32(uint32_t n) { uint32_t r = (uint32_t)sqrt((double)n); while (r * r > n) --r; while ((r + 1) * (r + 1) <= n) ++r; return r; }
+
+static ray camera_ray(const float* cam, const orc_params* p, uint32_t seed_k, uint32_t gx, uint32_t gy, uint32_t sample, uint32_t* key_out)
+{
+    float step = cam[19];
+    v3 pos = cam3(cam, 0), up = cam3(cam, 12), right = cam3(cam, 16);
+    v3 pc = pixel_corner(cam, gx, gy);
+    uint32_t key = orc_hash32(orc_hash32(seed_k ^ (gy * p->width + gx)) ^ sample);
+    *key_out = key;
+    v3 origin;
+    if (p->sample_mode == ORC_SAMPLE_JITTER) {
+        /* RayTracing.glsl:296 */
+        float s1 = step * orc_draw(key, DRAW_JITTER), s2 = step * orc_draw(key, DRAW_JITTER + 1);
+        origin = madd(-s2, up, madd(s1, right, pc));
+    } else {
+        /* renderPixel<N>, rayTracer.h:92-101 */
+        uint32_t N = p->grid_n;
+        uint32_t i = (sample / N) % N, j = sample % N;
+        float step_size = step / (float)(N + 1);                       /* :92 */
+        v3 ups = vscale(up, step_size), rs = vscale(right, step_size);
+        origin = vsub(pc, vscale(ups, (float)i));                      /* :97 */
+        if (p->sample_mode == ORC_SAMPLE_GRID_COMPAT) {
+            for (uint32_t jj = 0; jj <= j; ++jj) {                     /* :98-99, offset accumulates */
+                v3 inc = vscale(rs, (float)jj);
+                origin = V(origin.x + inc.x, origin.y + inc.y, origin.z + inc.z);
+            }
+        } else {
+            v3 inc = vscale(rs, (float)j);
+            origin = V(origin.x + inc.x, origin.y + inc.y, origin.z + inc.z);
+        }
+    }
+    ray r; r.o = origin; r.d = normalize(vsub(origin, pos));           /* rayTracer.h:100, glsl:297 */
+    return r;
+}
+
+void orc_camera_ray(const float camera[21], const orc_params* p, uint32_t gx, uint32_t gy, uint32_t sample, float origin[3], float dir[3])
+{
+    uint32_t key;
+    orc_params q = *p;
+    if (q.sample_mode != ORC_SAMPLE_JITTER && q.grid_n == 0) q.grid_n = isqrt_u32(q.first_sample + q.spp);
+    ray r = camera_ray(camera, &q, seed_key(p->seed), gx, gy, sample, &key);
+    origin[0] = r.o.x; origin[1] = r.o.y; origin[2] = r.o.z;
+    dir[0] = r.d.x; dir[1] = r.d.y; dir[2] = r.d.z;
+}
+
+static v3 path_color(tracer* T, uint32_t gx, uint32_t gy, uint32_t sample)
+{
+    uint32_t key;
+    ray r = camera_ray(T->cam, T->p, T->seed_k, gx, gy, sample, &key);
+    T->st.samples++;
+    if (T->p->semantics == ORC_SEM_GLSL) return ray_color_glsl(T, r, (int)T->p->max_depth, key);
+    if (T->p->color_order == ORC_COLOR_FORWARD) return ray_color_cpu_forward(T, r, (int)T->p->max_depth, key);
+    return ray_color_cpu_recursive(T, r, (int)T->p->max_depth - 1, key, 0);
+}
+
+/* uvec4(255 * color), RayTracing.glsl:301.  GLSL leaves negative and
+ * out-of-range conversions undefined; here they saturate and NaN gives 0. */
+static inline uint32_t quantise(float c)
+{
+    float v = 255.0f * c;
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)v;
+}
+
+static int row_in_shard(const orc_params* p, uint32_t y)
+{
+    if (p->shard_count <= 1) return 1;
+    uint32_t band = p->band_rows ? p->band_rows : 1;
+    return (y / band) % p->shard_count == p->shard_index;
+}
+
+static void stats_add(orc_stats* a, const orc_stats* b)
+{
+    a->samples += b->samples; a->segments += b->segments; a->diffuse += b->diffuse;
+    a->specular += b->specular; a->terminal += b->terminal; a->shape_tests += b->shape_tests;
+    a->sphere_tests += b->sphere_tests; a->box_tests += b->box_tests; a->triangle_tests += b->triangle_tests;
+}
+
+static int fix_params(const orc_params* in, orc_params* q)
+{
+    *q = *in;
+    if (q->width == 0 || q->height == 0 || q->max_depth == 0) return -1;
+    if (q->sample_mode != ORC_SAMPLE_JITTER) {
+        if (q->grid_n == 0) q->grid_n = isqrt_u32(q->first_sample + q->spp);
+        if (q->grid_n == 0) return -1;
+    }
+    return 0;
+}
+
+int orc_render(const orc_shape* shapes, uint32_t n_shapes, const orc_triangle* tris, uint32_t n_tris,
+               const float camera[21], const orc_params* pin, uint32_t* accum, orc_stats* stats)
+{
+    orc_params q;
+    if (fix_params(pin, &q)) return -1;
+    orc_stats total; memset(&total, 0, sizeof total);
+    int threads = q.threads;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#else
+    threads = 1;
+#endif
+    (void)threads;
+#pragma omp parallel num_threads(threads)
+    {
+        tracer T; memset(&T, 0, sizeof T);
+        T.shapes = shapes; T.n_shapes = n_shapes; T.tris = tris; T.n_tris = n_tris;
+        T.cam = camera; T.p = &q; T.seed_k = seed_key(q.seed);
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t y = 0; y < (int64_t)q.height; ++y) {
+            if (!row_in_shard(&q, (uint32_t)y)) continue;
+            for (uint32_t x = 0; x < q.width; ++x) {
+                uint32_t* px = accum + 4u * ((size_t)y * q.width + x);
+                if (q.semantics == ORC_SEM_GLSL) {
+                    uint32_t r = px[0], g = px[1], b = px[2];
+                    for (uint32_t s = 0; s < q.spp; ++s) {
+                        v3 c = path_color(&T, x, (uint32_t)y, q.first_sample + s);
+                        r += quantise(c.x); g += quantise(c.y); b += quantise(c.z);   /* glsl:301-307 */
+                    }
+                    px[0] = r; px[1] = g; px[2] = b;
+                } else {
+                    float f[3]; memcpy(f, px, sizeof f);
+                    for (uint32_t s = 0; s < q.spp; ++s) {                            /* rayTracer.h:96-103 */
+                        v3 c = path_color(&T, x, (uint32_t)y, q.first_sample + s);
+                        f[0] += c.x; f[1] += c.y; f[2] += c.z;
+                    }
+                    memcpy(px, f, sizeof f);
+                }
+            }
+        }
+#pragma omp critical
+        stats_add(&total, &T.st);
+    }
+    if (stats) *stats = total;
+    return 0;
+}
+
+int orc_trace(const orc_shape* shapes, uint32_t n_shapes, const orc_triangle* tris, uint32_t n_tris,
+              const float camera[21], const orc_params* pin, uint32_t sample,
+              int32_t* hit_index, uint32_t* material_id)
+{
+    orc_params q;
+    if (fix_params(pin, &q)) return -1;
+    tracer T; memset(&T, 0, sizeof T);
+    T.shapes = shapes; T.n_shapes = n_shapes; T.tris = tris; T.n_tris = n_tris;
+    T.cam = camera; T.p = &q; T.seed_k = seed_key(q.seed);
+    for (uint32_t y = 0; y < q.height; ++y)
+        for (uint32_t x = 0; x < q.width; ++x) {
+            size_t base = ((size_t)y * q.width + x) * q.max_depth;
+            for (uint32_t b = 0; b < q.max_depth; ++b) { hit_index[base + b] = -2; material_id[base + b] = 0xffffffffu; }
+            T.trace_hit = hit_index + base; T.trace_mat = material_id + base;
+            (void)path_color(&T, x, y, sample);
+        }
+    return 0;
+}
+
+/* rayTracer.h:105 (sum / totalRays, cwiseSqrt, row flip :78) and
+ * PixelConversion.glsl:17-20 (uint sum / (255 * samples)). */
+void orc_resolve(const uint32_t* accum, uint32_t width, uint32_t height, uint32_t samples,
+                 uint32_t semantics, int gamma_sqrt, int flip_rows, float* rgba)
+{
+    for (uint32_t y = 0; y < height; ++y) {
+        uint32_t oy = flip_rows ? height - 1 - y : y;
+        for (uint32_t x = 0; x < width; ++x) {
+            const uint32_t* px = accum + 4u * ((size_t)y * width + x);
+            float* o = rgba + 4u * ((size_t)oy * width + x);
+            for (int k = 0; k < 3; ++k) {
+                float v;
+                if (semantics == ORC_SEM_GLSL) v = (float)px[k] / (255.0f * (float)samples);
+                else { float f; memcpy(&f, &px[k], 4); v = f / (float)samples; }
+                o[k] = gamma_sqrt ? sqrtf(v) : v;
+            }
+            o[3] = 1.0f;
+        }
+    }
+}
+
+/* PixelConversion.glsl:12-28: running mean over frames, then clear. */
+void orc_convert(uint32_t* accum, float* image, uint32_t width, uint32_t height,
+                 uint32_t samples_in_accum, uint32_t semantics, uint32_t n_samples)
+{
+    float nf = (float)n_samples;
+    float wa = (nf - 1.0f) / nf, wb = 1.0f / nf;                       /* :22 */
+    for (uint32_t y = 0; y < height; ++y) {
+        uint32_t oy = height - 1 - y;
+        for (uint32_t x = 0; x < width; ++x) {
+            uint32_t* px = accum + 4u * ((size_t)y * width + x);
+            float* o = image + 4u * ((size_t)oy * width + x);
+            float cur[4];
+            for (int k = 0; k < 3; ++k) {
+                if (semantics == ORC_SEM_GLSL) cur[k] = (float)px[k] / (255.0f * (float)samples_in_accum);
+                else { float f; memcpy(&f, &px[k], 4); cur[k] = f / (float)samples_in_accum; }
+            }
+            cur[3] = 1.0f;                                             /* :20 */
+            for (int k = 0; k < 4; ++k)
+                o[k] = (nf != 1.0f) ? fmaf(wa, o[k], cur[k] * wb) : cur[k];   /* :21-24 */
+            px[0] = px[1] = px[2] = 0; px[3] = 0;                      /* :25-27 */
+        }
+    }
+}
+
+/* ------------------------------------------------- host-side constructors */
+
+/* Camera::Camera, src/gpu_version/camera.h:14-28 (rayTracer.h:37-46 is the
+ * same with position (1,0,6)). */
+void orc_camera_init(float data[21], uint32_t width, uint32_t height, float focal, const float pos[3])
+{
+    memset(data, 0, 21 * sizeof(float));
+    data[0] = pos[0]; data[1] = pos[1]; data[2] = pos[2];              /* :17 */
+    data[4] = 0; data[5] = 0; data[6] = -1;                            /* :18 */
+    data[12] = 0; data[13] = 1; data[14] = 0;                          /* :20 */
+    data[16] = 1; data[17] = 0; data[18] = 0;                          /* :21 */
+    unsigned int wh = width * height;
+    float world_w = (float)(width * (1 / sqrt((double)wh)));           /* :23 */
+    float world_h = (float)(height * (1 / sqrt((double)wh)));          /* :24 */
+    data[19] = world_w / (float)width;                                 /* :25 */
+    data[8] = -world_w / 2 + pos[0];                                   /* :26 */
+    data[9] = world_h / 2 + pos[1];
+    data[10] = -focal + pos[2];
+}
+
+/* SimpleTriangle::SimpleTriangle, shape.h:83-102.  Host arithmetic as Eigen
+ * evaluates it: no fused operations, sums left to right. */
+static inline float hdot(const float a[3], const float b[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+
+void orc_make_triangle(orc_triangle* out, const float p1[3], const float p2[3], const float p3[3])
+{
+    memset(out, 0, sizeof *out);
+    float v1[3], v2[3], n[3];
+    for (int k = 0; k < 3; ++k) { out->position[k] = p1[k]; v1[k] = p2[k] - p1[k]; v2[k] = p3[k] - p1[k]; }  /* :84-87 */
+    n[0] = v1[1] * v2[2] - v1[2] * v2[1];
+    n[1] = v1[2] * v2[0] - v1[0] * v2[2];
+    n[2] = v1[0] * v2[1] - v1[1] * v2[0];
+    float len = sqrtf(hdot(n, n));
+    for (int k = 0; k < 3; ++k) out->a[k] = n[k] / len;                /* :88 */
+    out->beta = hdot(out->a, p1);                                      /* :89 */
+    float f1 = hdot(v1, v2) / hdot(v2, v2), m1[3];
+    for (int k = 0; k < 3; ++k) m1[k] = v1[k] - f1 * v2[k];            /* :93 */
+    float d1 = hdot(m1, v1);
+    for (int k = 0; k < 3; ++k) out->m1[k] = m1[k] / d1;               /* :94 */
+    float f2 = hdot(v1, v2) / hdot(v1, v1), m2[3];
+    for (int k = 0; k < 3; ++k) m2[k] = v2[k] - f2 * v1[k];            /* :96 */
+    float d2 = hdot(m2, v2);
+    for (int k = 0; k < 3; ++k) out->m2[k] = m2[k] / d2;               /* :97 */
+}
+
+/* SimpleMesh::loadMesh (SimpleMesh.h:145-215), normalize (:60-77), resize
+ * (:79-85), transform (:122-126) and the triangle loop of main.cpp:113-122. */
+int orc_mesh_triangles(const char* path, int pipeline, orc_triangle* out, uint32_t max_tris, uint32_t* n_vertices)
+{
+    FILE* f = fopen(path, "r");
+    if (!f) return -1;
+    char tag[8] = { 0 };
+    unsigned nv = 0, np = 0, ne = 0;
+    if (fscanf(f, "%4s %u %u %u", tag, &nv, &np, &ne) != 4) { fclose(f); return -2; }
+    int coff = strcmp(tag, "COFF") == 0;
+    if (!coff && strcmp(tag, "OFF") != 0) { fclose(f); return -3; }
+    float* pos = (float*)malloc(sizeof(float) * 3 * (nv ? nv : 1));
+    for (unsigned i = 0; i < nv; ++i) {
+        if (fscanf(f, "%f %f %f", &pos[3 * i], &pos[3 * i + 1], &pos[3 * i + 2]) != 3) { free(pos); fclose(f); return -4; }
+        if (coff) { float c[4]; if (fscanf(f, "%f %f %f %f", &c[0], &c[1], &c[2], &c[3]) != 4) { free(pos); fclose(f); return -4; } }
+    }
+    if (pipeline) {
+        float c[3] = { 0, 0, 0 };
+        for (unsigned i = 0; i < nv; ++i) for (int k = 0; k < 3; ++k) c[k] += pos[3 * i + k];     /* :52-58 */
+        for (int k = 0; k < 3; ++k) c[k] = c[k] / (float)nv;
+        float radius = 0;
+        for (unsigned i = 0; i < nv; ++i) {                                                         /* :70-77 */
+            float d[3] = { pos[3 * i] - c[0], pos[3 * i + 1] - c[1], pos[3 * i + 2] - c[2] };
+            float nrm = sqrtf(hdot(d, d));
+            if (nrm > radius) radius = nrm;
+        }
+        const float ang = (float)(-3.14159265358979323846 / 2);                                    /* main.cpp:112 */
+        const float cs = cosf(ang), sn = sinf(ang);
+        /* 0.5 * AngleAxisf(ang, UnitX).toRotationMatrix() */
+        const float R[9] = { 0.5f * 1.0f, 0.5f * 0.0f, 0.5f * 0.0f,
+                             0.5f * 0.0f, 0.5f * cs,   0.5f * -sn,
+                             0.5f * 0.0f, 0.5f * sn,   0.5f * cs };
+        const float tr[3] = { 0.5f, 0.7f, -2.0f };
+        for (unsigned i = 0; i < nv; ++i) {
+            float v[3];
+            for (int k = 0; k < 3; ++k) v[k] = (pos[3 * i + k] - c[k]) / radius;                    /* :66 */
+            for (int k = 0; k < 3; ++k) v[k] = v[k] * 2.0f;                                         /* :81-84 */
+            for (int k = 0; k < 3; ++k)
+                pos[3 * i + k] = ((R[3 * k] * v[0] + R[3 * k + 1] * v[1]) + R[3 * k + 2] * v[2]) + tr[k];   /* :124 */
+        }
+    }
+    uint32_t count = 0;
+    for (unsigned i = 0; i < np; ++i) {
+        unsigned k, a, b, c;
+        if (fscanf(f, "%u %u %u %u", &k, &a, &b, &c) != 4 || k != 3 || a >= nv || b >= nv || c >= nv) { free(pos); fclose(f); return -5; }
+        if (count < max_tris) orc_make_triangle(&out[count], &pos[3 * a], &pos[3 * b], &pos[3 * c]);
+        ++count;
+    }
+    if (n_vertices) *n_vertices = nv;
+    free(pos); fclose(f);
+    return (int)count;
+}

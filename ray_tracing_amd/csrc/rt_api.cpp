@@ -1,0 +1,484 @@
+// rt_api.cpp — the C ABI of include/rt_mi355x.h on top of the HIP kernels.
+//
+// Owns the device copies of the scene (repacked from the reference's 144-byte
+// Shape to the 48-byte DevShape), the accumulator, the running-mean image and
+// the statistics block.  Every HIP return code is checked and turned into an
+// rt_status plus a message; nothing throws across the boundary.  There is no
+// CPU fallback: without a HIP device rt_create fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_mi355x.h"
+#include "rt_device.h"
+
+namespace rtd {
+hipError_t launch_trace(int sem, bool stats, bool trace, dim3 grid, hipStream_t stream,
+                        const TraceParams& P, const DevShape* shapes, const DevTriangle* tris,
+                        uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm);
+hipError_t launch_trace_fill(hipStream_t stream, int32_t* hit, uint32_t* mat, size_t n);
+hipError_t launch_resolve(int sem, hipStream_t stream, const uint32_t* accum, float* out, uint32_t w, uint32_t h,
+                          uint32_t samples, int gamma_sqrt, int flip_rows);
+hipError_t launch_convert(int sem, hipStream_t stream, uint32_t* accum, float* image, uint32_t w, uint32_t h,
+                          uint32_t samples, uint32_t n_samples);
+}  // namespace rtd
+
+static_assert(sizeof(rt_material) == 32, "Material layout (shape.h:5-12)");
+static_assert(sizeof(rt_shape) == 144, "Shape layout (shape.h:44-54)");
+static_assert(offsetof(rt_shape, type) == 64 && offsetof(rt_shape, data) == 68 && offsetof(rt_shape, material) == 112,
+              "Shape field offsets (RayTracing.glsl:92-97)");
+static_assert(sizeof(rt_triangle) == 64 && offsetof(rt_triangle, a) == 16 && offsetof(rt_triangle, beta) == 28 &&
+              offsetof(rt_triangle, m1) == 32 && offsetof(rt_triangle, m2) == 48,
+              "SimpleTriangle layout (shape.h:103-108, RayTracing.glsl:10-16)");
+
+struct rt_ctx {
+    rt_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    rtd::DevShape* d_shapes = nullptr;   uint32_t n_shapes = 0, cap_shapes = 0;
+    rtd::DevTriangle* d_tris = nullptr;  uint32_t n_tris = 0, cap_tris = 0;
+    float cam[RT_CAMERA_FLOATS] = {};
+    bool have_camera = false;
+
+    uint32_t* d_accum = nullptr;         // owned accumulator
+    uint32_t* d_accum_ext = nullptr;     // caller-owned accumulator, if bound
+    uint32_t width = 0, height = 0;      // dimensions of the accumulator in use
+    uint32_t accum_samples = 0;
+    float* d_image = nullptr;            // running mean (rt_convert)
+    uint32_t image_w = 0, image_h = 0;
+
+    uint32_t shard_index = 0, shard_count = 1, band_rows = 16;
+
+    unsigned long long* d_stats = nullptr;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(rt_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define RT_HIP(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP,       \
+                        "%s failed: %s", #call, hipGetErrorString(e_));                           \
+    } while (0)
+
+#define RT_REQUIRE(ctx, cond, msg)                                                                \
+    do { if (!(cond)) return fail(ctx, RT_ERR_INVALID_ARG, "%s", msg); } while (0)
+
+static uint32_t hash32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+static uint32_t seed_key(uint64_t seed)
+{
+    return hash32((uint32_t)seed ^ hash32((uint32_t)(seed >> 32) ^ 0x85ebca6bu));
+}
+
+extern "C" {
+
+int rt_create(rt_ctx** out, const rt_config* cfg)
+{
+    if (!out) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: out is NULL");
+    *out = nullptr;
+    rt_config c{};
+    c.struct_size = sizeof(rt_config);
+    c.triangle_albedo[0] = 1.0f;           // RayTracing.glsl:275
+    if (cfg) {
+        if (cfg->struct_size != sizeof(rt_config))
+            return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: struct_size %u, expected %zu", cfg->struct_size, sizeof(rt_config));
+        c = *cfg;
+    }
+    if (c.semantics > RT_SEM_GLSL) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown semantics %u", c.semantics);
+    if (c.sample_mode > RT_SAMPLE_GRID_COMPAT) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown sample_mode %u", c.sample_mode);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, RT_ERR_NO_DEVICE, "rt_create: no HIP device (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    if (c.device < 0 || c.device >= count)
+        return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: device %d out of range [0,%d)", c.device, count);
+    e = hipSetDevice(c.device);
+    if (e != hipSuccess) return fail(nullptr, RT_ERR_HIP, "hipSetDevice(%d): %s", c.device, hipGetErrorString(e));
+    rt_ctx* ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) return fail(nullptr, RT_ERR_OUT_OF_MEMORY, "rt_create: host allocation failed");
+    ctx->cfg = c;
+    ctx->device = c.device;
+    e = hipMalloc(&ctx->d_stats, sizeof(unsigned long long) * rtd::ST_COUNT);
+    if (e != hipSuccess) { delete ctx; return fail(nullptr, RT_ERR_OUT_OF_MEMORY, "hipMalloc(stats): %s", hipGetErrorString(e)); }
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->d_shapes);
+    (void)hipFree(ctx->d_tris);
+    (void)hipFree(ctx->d_accum);
+    (void)hipFree(ctx->d_image);
+    (void)hipFree(ctx->d_stats);
+    delete ctx;
+}
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rt_set_stream(rt_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return RT_OK;
+}
+
+int rt_upload_shapes(rt_ctx* ctx, const rt_shape* shapes, uint32_t n)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_REQUIRE(ctx, n == 0 || shapes, "rt_upload_shapes: shapes is NULL");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<rtd::DevShape> packed(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const rt_shape& s = shapes[i];
+        rtd::DevShape& d = packed[i];
+        d.cx = s.transformation[12]; d.cy = s.transformation[13]; d.cz = s.transformation[14];
+        const float scale = s.transformation[0];
+        d.type = s.type;
+        if (s.type == RT_SHAPE_CIRCLE) { d.p0 = scale * scale; d.p1 = 0.0f; }
+        else { d.p0 = scale; d.p1 = 1.0f / scale; }
+        d.mat_type = s.material.type;
+        d.fuzz = s.material.data[1];
+        d.r = s.material.color[0]; d.g = s.material.color[1]; d.b = s.material.color[2];
+        d.ior = s.material.data[0];
+    }
+    // The kernels may still be reading the old copy.
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n > ctx->cap_shapes) {
+        RT_HIP(ctx, hipFree(ctx->d_shapes));
+        ctx->d_shapes = nullptr; ctx->cap_shapes = 0;
+        RT_HIP(ctx, hipMalloc(&ctx->d_shapes, sizeof(rtd::DevShape) * n));
+        ctx->cap_shapes = n;
+    }
+    if (n) RT_HIP(ctx, hipMemcpy(ctx->d_shapes, packed.data(), sizeof(rtd::DevShape) * n, hipMemcpyHostToDevice));
+    ctx->n_shapes = n;
+    return RT_OK;
+}
+
+int rt_upload_triangles(rt_ctx* ctx, const rt_triangle* tris, uint32_t n)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_REQUIRE(ctx, n == 0 || tris, "rt_upload_triangles: triangles is NULL");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n > ctx->cap_tris) {
+        RT_HIP(ctx, hipFree(ctx->d_tris));
+        ctx->d_tris = nullptr; ctx->cap_tris = 0;
+        RT_HIP(ctx, hipMalloc(&ctx->d_tris, sizeof(rtd::DevTriangle) * n));
+        ctx->cap_tris = n;
+    }
+    if (n) RT_HIP(ctx, hipMemcpy(ctx->d_tris, tris, sizeof(rtd::DevTriangle) * n, hipMemcpyHostToDevice));
+    ctx->n_tris = n;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_ctx* ctx, const float data[RT_CAMERA_FLOATS])
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_REQUIRE(ctx, data, "rt_set_camera: data is NULL");
+    memcpy(ctx->cam, data, sizeof ctx->cam);
+    ctx->have_camera = true;
+    return RT_OK;
+}
+
+int rt_set_row_shard(rt_ctx* ctx, uint32_t shard_index, uint32_t shard_count, uint32_t band_rows)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_REQUIRE(ctx, shard_count >= 1 && shard_index < shard_count, "rt_set_row_shard: need shard_index < shard_count");
+    RT_REQUIRE(ctx, band_rows >= 1, "rt_set_row_shard: band_rows must be >= 1");
+    ctx->shard_index = shard_index; ctx->shard_count = shard_count; ctx->band_rows = band_rows;
+    return RT_OK;
+}
+
+int rt_bind_accum(rt_ctx* ctx, void* device_words, uint32_t width, uint32_t height)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    if (!device_words) { ctx->d_accum_ext = nullptr; if (!ctx->d_accum) { ctx->width = ctx->height = 0; } ctx->accum_samples = 0; return RT_OK; }
+    RT_REQUIRE(ctx, width > 0 && height > 0, "rt_bind_accum: empty image");
+    RT_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(device_words) & 15u) == 0, "rt_bind_accum: buffer must be 16-byte aligned");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_accum) { RT_HIP(ctx, hipFree(ctx->d_accum)); ctx->d_accum = nullptr; }
+    ctx->d_accum_ext = static_cast<uint32_t*>(device_words);
+    ctx->width = width; ctx->height = height;
+    ctx->accum_samples = 0;
+    return RT_OK;
+}
+
+static uint32_t* accum_ptr(rt_ctx* ctx) { return ctx->d_accum_ext ? ctx->d_accum_ext : ctx->d_accum; }
+
+// Makes sure an accumulator of width x height exists (zeroed when created).
+static int ensure_accum(rt_ctx* ctx, uint32_t width, uint32_t height)
+{
+    if (ctx->d_accum_ext) {
+        if (ctx->width != width || ctx->height != height)
+            return fail(ctx, RT_ERR_INVALID_ARG, "render size %ux%u differs from the bound accumulator %ux%u", width, height, ctx->width, ctx->height);
+        return RT_OK;
+    }
+    if (ctx->d_accum && ctx->width == width && ctx->height == height) return RT_OK;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_accum) { RT_HIP(ctx, hipFree(ctx->d_accum)); ctx->d_accum = nullptr; }
+    const size_t bytes = (size_t)width * height * 16u;
+    RT_HIP(ctx, hipMalloc(&ctx->d_accum, bytes));
+    RT_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, bytes, ctx->stream));
+    ctx->width = width; ctx->height = height; ctx->accum_samples = 0;
+    return RT_OK;
+}
+
+static uint32_t isqrt_u32(uint32_t n)
+{
+    uint32_t r = (uint32_t)std::sqrt((double)n);
+    while ((uint64_t)r * r > n) --r;
+    while ((uint64_t)(r + 1) * (r + 1) <= n) ++r;
+    return r;
+}
+
+static uint32_t owned_rows(const rt_ctx* ctx, uint32_t height)
+{
+    if (ctx->shard_count <= 1) return height;
+    const uint32_t band = ctx->band_rows;
+    const uint32_t n_bands = (height + band - 1) / band;
+    uint32_t rows = 0;
+    for (uint32_t b = ctx->shard_index; b < n_bands; b += ctx->shard_count) {
+        uint32_t y0 = b * band, y1 = y0 + band; if (y1 > height) y1 = height;
+        rows += y1 - y0;
+    }
+    return rows;
+}
+
+static int fill_params(rt_ctx* ctx, rtd::TraceParams& P, uint32_t width, uint32_t height, uint32_t spp,
+                       uint32_t max_depth, uint64_t seed, uint32_t first_sample, uint32_t grid_n)
+{
+    RT_REQUIRE(ctx, width > 0 && height > 0, "render: empty image");
+    RT_REQUIRE(ctx, (uint64_t)width * height <= 0x0fffffffu, "render: image too large (pixel index must fit 28 bits)");
+    RT_REQUIRE(ctx, max_depth >= 1 && max_depth <= 1024, "render: max_depth must be in [1,1024]");
+    RT_REQUIRE(ctx, (uint64_t)first_sample + spp <= 0xffffffffu, "render: sample range overflows");
+    RT_REQUIRE(ctx, ctx->have_camera, "render: rt_set_camera has not been called");
+    memset(&P, 0, sizeof P);
+    memcpy(P.cam, ctx->cam, sizeof P.cam);
+    memcpy(P.tri_albedo, ctx->cfg.triangle_albedo, sizeof P.tri_albedo);
+    P.width = width; P.height = height;
+    P.n_shapes = ctx->n_shapes; P.n_tris = ctx->n_tris;
+    P.spp = spp; P.first_sample = first_sample; P.max_depth = max_depth;
+    P.seed_key = seed_key(seed);
+    P.sample_mode = ctx->cfg.sample_mode; P.flags = ctx->cfg.flags;
+    if (P.sample_mode != RT_SAMPLE_JITTER) {
+        if (grid_n == 0) {
+            grid_n = isqrt_u32(first_sample + spp);
+            RT_REQUIRE(ctx, grid_n * grid_n == first_sample + spp, "render: grid sample mode needs first_sample + spp to be a square (or pass grid_n)");
+        }
+        RT_REQUIRE(ctx, grid_n >= 1, "render: grid_n must be >= 1");
+    }
+    P.grid_n = grid_n ? grid_n : 1u;
+    if (ctx->shard_count <= 1) { P.shard_index = 0; P.shard_count = 1; P.band_rows = height; }
+    else { P.shard_index = ctx->shard_index; P.shard_count = ctx->shard_count; P.band_rows = ctx->band_rows; }
+    P.owned_rows = owned_rows(ctx, height);
+    return RT_OK;
+}
+
+static dim3 trace_grid(const rtd::TraceParams& P)
+{
+    return dim3((P.width + rtd::TILE_W - 1) / rtd::TILE_W, (P.owned_rows + rtd::TILE_H - 1) / rtd::TILE_H);
+}
+
+static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth,
+                       uint64_t seed, uint32_t first_sample, uint32_t grid_n, rt_stats* stats)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    rtd::TraceParams P;
+    int rc = fill_params(ctx, P, width, height, spp, max_depth, seed, first_sample, grid_n);
+    if (rc) return rc;
+    rc = ensure_accum(ctx, width, height);
+    if (rc) return rc;
+    if (stats) RT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * rtd::ST_COUNT, ctx->stream));
+    if (spp > 0 && P.owned_rows > 0) {
+        RT_HIP(ctx, rtd::launch_trace((int)ctx->cfg.semantics, stats != nullptr, false, trace_grid(P), ctx->stream, P,
+                                      ctx->d_shapes, ctx->d_tris, accum_ptr(ctx), ctx->d_stats, nullptr, nullptr));
+    }
+    ctx->accum_samples += spp;
+    if (stats) {
+        unsigned long long h[rtd::ST_COUNT];
+        RT_HIP(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memset(stats, 0, sizeof *stats);
+        stats->samples = h[rtd::ST_SAMPLES]; stats->segments = h[rtd::ST_SEGMENTS];
+        stats->diffuse = h[rtd::ST_DIFFUSE]; stats->specular = h[rtd::ST_SPECULAR];
+        stats->terminal = h[rtd::ST_TERMINAL];
+        // Every segment tests every primitive (the reference's closest-hit
+        // loops are exhaustive), so the test counts follow from the segments.
+        uint64_t n_sph = 0, n_box = 0;
+        if (ctx->n_shapes) {
+            std::vector<rtd::DevShape> host(ctx->n_shapes);
+            RT_HIP(ctx, hipMemcpy(host.data(), ctx->d_shapes, sizeof(rtd::DevShape) * ctx->n_shapes, hipMemcpyDeviceToHost));
+            for (const auto& s : host) { if (s.type == RT_SHAPE_CIRCLE) ++n_sph; else if (s.type == RT_SHAPE_BOX) ++n_box; }
+        }
+        stats->shape_tests = stats->segments * ctx->n_shapes;
+        stats->sphere_tests = stats->segments * n_sph;
+        stats->box_tests = stats->segments * n_box;
+        stats->triangle_tests = stats->segments * ctx->n_tris;
+    }
+    return RT_OK;
+}
+
+int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth,
+              uint64_t seed, uint32_t first_sample, uint32_t grid_n)
+{
+    return render_impl(ctx, width, height, spp, max_depth, seed, first_sample, grid_n, nullptr);
+}
+
+int rt_render_stats(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth,
+                    uint64_t seed, uint32_t first_sample, uint32_t grid_n, rt_stats* out)
+{
+    if (ctx && !out) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render_stats: out is NULL");
+    return render_impl(ctx, width, height, spp, max_depth, seed, first_sample, grid_n, out);
+}
+
+int rt_accum_samples(const rt_ctx* ctx, uint32_t* out)
+{
+    if (!ctx || !out) return RT_ERR_INVALID_ARG;
+    *out = ctx->accum_samples;
+    return RT_OK;
+}
+
+int rt_reset_accum(rt_ctx* ctx)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (accum_ptr(ctx))
+        RT_HIP(ctx, hipMemsetAsync(accum_ptr(ctx), 0, (size_t)ctx->width * ctx->height * 16u, ctx->stream));
+    ctx->accum_samples = 0;
+    return RT_OK;
+}
+
+int rt_resolve_device(rt_ctx* ctx, float* rgba_device, int gamma_sqrt, int flip_rows)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_REQUIRE(ctx, rgba_device, "rt_resolve_device: output is NULL");
+    if (!accum_ptr(ctx) || ctx->accum_samples == 0) return fail(ctx, RT_ERR_STATE, "resolve: nothing has been rendered");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, rtd::launch_resolve((int)ctx->cfg.semantics, ctx->stream, accum_ptr(ctx), rgba_device, ctx->width, ctx->height,
+                                    ctx->accum_samples, gamma_sqrt, flip_rows));
+    return RT_OK;
+}
+
+int rt_resolve(rt_ctx* ctx, float* rgba_host, int gamma_sqrt, int flip_rows)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_REQUIRE(ctx, rgba_host, "rt_resolve: output is NULL");
+    if (!accum_ptr(ctx) || ctx->accum_samples == 0) return fail(ctx, RT_ERR_STATE, "resolve: nothing has been rendered");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)ctx->width * ctx->height * 16u;
+    float* tmp = nullptr;
+    RT_HIP(ctx, hipMalloc(&tmp, bytes));
+    int rc = rt_resolve_device(ctx, tmp, gamma_sqrt, flip_rows);
+    if (rc == RT_OK) {
+        hipError_t e = hipMemcpyAsync(rgba_host, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "resolve copy-back failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(tmp);
+    return rc;
+}
+
+int rt_convert(rt_ctx* ctx, uint32_t n_samples)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_REQUIRE(ctx, n_samples >= 1, "rt_convert: n_samples starts at 1 (main.cpp:42)");
+    if (!accum_ptr(ctx) || ctx->accum_samples == 0) return fail(ctx, RT_ERR_STATE, "convert: nothing has been rendered");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_image || ctx->image_w != ctx->width || ctx->image_h != ctx->height) {
+        RT_REQUIRE(ctx, n_samples == 1 || !ctx->d_image ? true : false, "rt_convert: image size changed; restart with n_samples = 1");
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_image) { RT_HIP(ctx, hipFree(ctx->d_image)); ctx->d_image = nullptr; }
+        const size_t bytes = (size_t)ctx->width * ctx->height * 16u;
+        RT_HIP(ctx, hipMalloc(&ctx->d_image, bytes));
+        RT_HIP(ctx, hipMemsetAsync(ctx->d_image, 0, bytes, ctx->stream));
+        ctx->image_w = ctx->width; ctx->image_h = ctx->height;
+    }
+    RT_HIP(ctx, rtd::launch_convert((int)ctx->cfg.semantics, ctx->stream, accum_ptr(ctx), ctx->d_image, ctx->width, ctx->height,
+                                    ctx->accum_samples, n_samples));
+    ctx->accum_samples = 0;
+    return RT_OK;
+}
+
+int rt_read_image(rt_ctx* ctx, float* rgba_host)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_REQUIRE(ctx, rgba_host, "rt_read_image: output is NULL");
+    if (!ctx->d_image) return fail(ctx, RT_ERR_STATE, "rt_read_image: rt_convert has not run");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipMemcpyAsync(rgba_host, ctx->d_image, (size_t)ctx->image_w * ctx->image_h * 16u, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_trace_debug(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t max_depth, uint64_t seed,
+                   uint32_t sample, uint32_t grid_n, int32_t* hit_index_host, uint32_t* material_id_host)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_REQUIRE(ctx, hit_index_host && material_id_host, "rt_trace_debug: output is NULL");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    rtd::TraceParams P;
+    // The trace ignores sharding: it follows every pixel.
+    const uint32_t si = ctx->shard_index, sc = ctx->shard_count;
+    ctx->shard_index = 0; ctx->shard_count = 1;
+    int rc = fill_params(ctx, P, width, height, 1, max_depth, seed, sample, grid_n ? grid_n : (ctx->cfg.sample_mode ? 0u : 1u));
+    ctx->shard_index = si; ctx->shard_count = sc;
+    if (rc) return rc;
+    P.trace_sample = sample;
+    const size_t n = (size_t)width * height * max_depth;
+    int32_t* d_hit = nullptr; uint32_t* d_mat = nullptr;
+    RT_HIP(ctx, hipMalloc(&d_hit, n * sizeof(int32_t)));
+    hipError_t e = hipMalloc(&d_mat, n * sizeof(uint32_t));
+    if (e != hipSuccess) { (void)hipFree(d_hit); return fail(ctx, RT_ERR_OUT_OF_MEMORY, "hipMalloc(trace): %s", hipGetErrorString(e)); }
+    e = rtd::launch_trace_fill(ctx->stream, d_hit, d_mat, n);
+    // accum is not touched by a TRACE launch; pass any valid pointer.
+    if (e == hipSuccess)
+        e = rtd::launch_trace((int)ctx->cfg.semantics, false, true, trace_grid(P), ctx->stream, P, ctx->d_shapes, ctx->d_tris,
+                              reinterpret_cast<uint32_t*>(d_hit), ctx->d_stats, d_hit, d_mat);
+    if (e == hipSuccess) e = hipMemcpyAsync(hit_index_host, d_hit, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(material_id_host, d_mat, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_hit); (void)hipFree(d_mat);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_trace_debug failed: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_device_info(int device, char* name, size_t name_len, int* compute_units, int* clock_mhz)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return RT_ERR_NO_DEVICE;
+    if (name && name_len) { snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName); }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = prop.clockRate / 1000;
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,273 @@
+// rt_host.cpp — host-side scene construction behind the C ABI: the reference's
+// Camera, Circle/Box, SimpleTriangle and SimpleMesh constructors in plain C++,
+// without Eigen, producing byte-identical structs.
+//
+// Host arithmetic follows the expressions of the reference as Eigen evaluates
+// them (no fused operations, three-term sums left to right); this file is
+// compiled with -ffp-contract=off.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_mi355x.h"
+
+namespace {
+
+struct Vec3 { float x, y, z; };
+inline Vec3 operator+(Vec3 a, Vec3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+inline Vec3 operator-(Vec3 a, Vec3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+inline Vec3 operator*(Vec3 a, float s) { return { a.x * s, a.y * s, a.z * s }; }
+inline Vec3 operator/(Vec3 a, float s) { return { a.x / s, a.y / s, a.z / s }; }
+inline float dot(Vec3 a, Vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline Vec3 cross(Vec3 a, Vec3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+inline Vec3 load3(const float* p) { return { p[0], p[1], p[2] }; }
+inline void store3(float* p, Vec3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+
+struct Mat3 { float m[3][3]; };   // row-major
+inline Vec3 mul(const Mat3& r, Vec3 v)
+{
+    return { (r.m[0][0] * v.x + r.m[0][1] * v.y) + r.m[0][2] * v.z,
+             (r.m[1][0] * v.x + r.m[1][1] * v.y) + r.m[1][2] * v.z,
+             (r.m[2][0] * v.x + r.m[2][1] * v.y) + r.m[2][2] * v.z };
+}
+inline Mat3 mul(const Mat3& a, const Mat3& b)
+{
+    Mat3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            r.m[i][j] = (a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j]) + a.m[i][2] * b.m[2][j];
+    return r;
+}
+// Rotation by `angle` about the unit `axis` (Rodrigues), the matrix
+// Eigen::AngleAxisf(angle, axis).toRotationMatrix() stands for in camera.h:86-87.
+Mat3 angle_axis(float angle, Vec3 axis)
+{
+    const float s = std::sin(angle), c = std::cos(angle);
+    const Vec3 sa = axis * s, ca = axis * (1.0f - c);
+    Mat3 r;
+    float t;
+    t = ca.x * axis.y; r.m[0][1] = t - sa.z; r.m[1][0] = t + sa.z;
+    t = ca.x * axis.z; r.m[0][2] = t + sa.y; r.m[2][0] = t - sa.y;
+    t = ca.y * axis.z; r.m[1][2] = t - sa.x; r.m[2][1] = t + sa.x;
+    r.m[0][0] = ca.x * axis.x + c; r.m[1][1] = ca.y * axis.y + c; r.m[2][2] = ca.z * axis.z + c;
+    return r;
+}
+
+// worldWidth / worldHeight of camera.h:23-24: unsigned product, double sqrt,
+// narrowed to float on assignment.
+void world_extent(uint32_t width, uint32_t height, float& ww, float& wh)
+{
+    const unsigned int area = width * height;
+    ww = (float)(width * (1 / std::sqrt((double)area)));
+    wh = (float)(height * (1 / std::sqrt((double)area)));
+}
+
+// setUpperLeft(...) of camera.h:91,112.
+void update_upper_left(float* data, uint32_t width, uint32_t height, float focal)
+{
+    float ww, wh; world_extent(width, height, ww, wh);
+    const Vec3 right = load3(data + 16), up = load3(data + 12), dir = load3(data + 4), pos = load3(data);
+    store3(data + 8, ((right * (-ww / 2)) + (up * (wh / 2))) + dir * focal + pos);
+}
+
+}  // namespace
+
+struct rt_mesh {
+    struct Vertex { float position[4]; float color[4]; float normal[3]; };   // SimpleMesh.h:24-30
+    std::vector<Vertex> vertices;
+    std::vector<uint32_t> indices;     // three per face (SimpleMesh.h:32-41)
+};
+
+extern "C" {
+
+// Camera::Camera, src/gpu_version/camera.h:14-28.
+void rt_camera_init(float data[RT_CAMERA_FLOATS], uint32_t width, uint32_t height, float focal, const float position[3])
+{
+    memset(data, 0, sizeof(float) * RT_CAMERA_FLOATS);                    // :15
+    store3(data + 0, load3(position));                                    // :17
+    store3(data + 4, { 0, 0, -1 });                                       // :18
+    store3(data + 12, { 0, 1, 0 });                                       // :20
+    store3(data + 16, { 1, 0, 0 });                                       // :21
+    float ww, wh; world_extent(width, height, ww, wh);                    // :23-24
+    data[19] = ww / (float)width;                                         // :25
+    store3(data + 8, Vec3{ -ww / 2, wh / 2, -focal } + load3(position));  // :26
+}
+
+// Camera::rotate, camera.h:85-92.
+void rt_camera_rotate(float data[RT_CAMERA_FLOATS], uint32_t width, uint32_t height, float focal, float horizontal, float vertical)
+{
+    Mat3 rot = angle_axis(horizontal, load3(data + 12));
+    rot = mul(angle_axis(vertical, mul(rot, load3(data + 16))), rot);
+    store3(data + 12, mul(rot, load3(data + 12)));
+    store3(data + 16, mul(rot, load3(data + 16)));
+    store3(data + 4, mul(rot, load3(data + 4)));
+    update_upper_left(data, width, height, focal);
+}
+
+// Camera::move, camera.h:94-113.
+void rt_camera_move(float data[RT_CAMERA_FLOATS], uint32_t width, uint32_t height, float focal, int direction)
+{
+    const Vec3 pos = load3(data), dir = load3(data + 4), right = load3(data + 16);
+    switch (direction) {
+    case 0: store3(data, pos + dir * 0.2f); break;
+    case 1: store3(data, pos - dir * 0.2f); break;
+    case 2: store3(data, pos + right * 0.2f); break;
+    case 3: store3(data, pos - right * 0.2f); break;
+    default: break;
+    }
+    update_upper_left(data, width, height, focal);
+}
+
+static void shape_base(rt_shape* out, uint32_t type, const rt_material* material)
+{
+    memset(out, 0, sizeof *out);
+    out->transformation[0] = out->transformation[5] = out->transformation[10] = out->transformation[15] = 1.0f;  // shape.h:47
+    out->type = type;
+    if (material) out->material = *material;
+}
+
+// Circle::Circle, shape.h:58-61.
+void rt_make_circle(rt_shape* out, const float translation[3], float radius, const rt_material* material)
+{
+    shape_base(out, RT_SHAPE_CIRCLE, material);
+    out->transformation[12] = translation[0]; out->transformation[13] = translation[1]; out->transformation[14] = translation[2];
+    out->transformation[0] = radius;
+}
+
+// Box::Box, shape.h:66-69.
+void rt_make_box(rt_shape* out, const float translation[3], const float sides[3], const rt_material* material)
+{
+    shape_base(out, RT_SHAPE_BOX, material);
+    out->transformation[0] = sides[0]; out->transformation[5] = sides[1]; out->transformation[10] = sides[2];
+    out->transformation[12] = translation[0]; out->transformation[13] = translation[1]; out->transformation[14] = translation[2];
+}
+
+// SimpleTriangle::SimpleTriangle, shape.h:83-102.
+void rt_make_triangle(rt_triangle* out, const float p1[3], const float p2[3], const float p3[3])
+{
+    memset(out, 0, sizeof *out);
+    const Vec3 a1 = load3(p1);
+    store3(out->position, a1);                                   // :84
+    const Vec3 v1 = load3(p2) - a1, v2 = load3(p3) - a1;         // :86-87
+    const Vec3 c = cross(v1, v2);
+    const Vec3 a = c / std::sqrt(dot(c, c));                     // :88
+    store3(out->a, a);
+    out->beta = dot(a, a1);                                      // :89
+    Vec3 m1 = v1 - v2 * (dot(v1, v2) / dot(v2, v2));             // :93
+    m1 = m1 / dot(m1, v1);                                       // :94
+    Vec3 m2 = v2 - v1 * (dot(v1, v2) / dot(v1, v1));             // :96
+    m2 = m2 / dot(m2, v2);                                       // :97
+    store3(out->m1, m1); store3(out->m2, m2);
+}
+
+// SimpleMesh::loadMesh, src/SimpleMesh.h:145-215.
+int rt_mesh_load(rt_mesh** out, const char* path)
+{
+    if (!out || !path) return RT_ERR_INVALID_ARG;
+    *out = nullptr;
+    FILE* f = fopen(path, "r");
+    if (!f) return RT_ERR_IO;                                    // :151-154
+    char tag[8] = { 0 };
+    unsigned nv = 0, np = 0, ne = 0;
+    if (fscanf(f, "%4s", tag) != 1 || fscanf(f, "%u %u %u", &nv, &np, &ne) != 3) { fclose(f); return RT_ERR_IO; }
+    const bool coff = strcmp(tag, "COFF") == 0;
+    if (!coff && strcmp(tag, "OFF") != 0) { fclose(f); return RT_ERR_IO; }   // :198-201
+    rt_mesh* mesh = new (std::nothrow) rt_mesh();
+    if (!mesh) { fclose(f); return RT_ERR_OUT_OF_MEMORY; }
+    mesh->vertices.reserve(nv); mesh->indices.reserve((size_t)np * 3);
+    for (unsigned i = 0; i < nv; ++i) {
+        rt_mesh::Vertex v{};
+        if (fscanf(f, "%f %f %f", &v.position[0], &v.position[1], &v.position[2]) != 3) { delete mesh; fclose(f); return RT_ERR_IO; }
+        v.position[3] = 1.0f;                                    // :175,190
+        if (coff) {
+            float c[4];
+            if (fscanf(f, "%f %f %f %f", &c[0], &c[1], &c[2], &c[3]) != 4) { delete mesh; fclose(f); return RT_ERR_IO; }
+            for (int k = 0; k < 4; ++k) v.color[k] = c[k] / 255;  // :179
+        } else {
+            v.color[3] = 255;                                    // :191-194
+        }
+        mesh->vertices.push_back(v);
+    }
+    for (unsigned i = 0; i < np; ++i) {
+        unsigned k = 0, a = 0, b = 0, c = 0;
+        if (fscanf(f, "%u", &k) != 1 || k != 3 ||                // :207 (triangles only)
+            fscanf(f, "%u %u %u", &a, &b, &c) != 3 || a >= nv || b >= nv || c >= nv) { delete mesh; fclose(f); return RT_ERR_IO; }
+        mesh->indices.push_back(a); mesh->indices.push_back(b); mesh->indices.push_back(c);
+    }
+    fclose(f);
+    *out = mesh;
+    return RT_OK;
+}
+
+void rt_mesh_free(rt_mesh* mesh) { delete mesh; }
+uint32_t rt_mesh_vertex_count(const rt_mesh* mesh) { return mesh ? (uint32_t)mesh->vertices.size() : 0; }
+uint32_t rt_mesh_triangle_count(const rt_mesh* mesh) { return mesh ? (uint32_t)(mesh->indices.size() / 3) : 0; }
+
+// get_mesh_center / get_mesh_center_and_radius, SimpleMesh.h:52-58,70-77.
+static void center_and_radius(const rt_mesh* mesh, Vec3& center, float& radius)
+{
+    center = { 0, 0, 0 };
+    for (const auto& v : mesh->vertices) center = center + load3(v.position);
+    center = center / (float)mesh->vertices.size();
+    radius = 0;
+    for (const auto& v : mesh->vertices) {
+        const Vec3 d = load3(v.position) - center;
+        radius = std::max(std::sqrt(dot(d, d)), radius);
+    }
+}
+
+// SimpleMesh::normalize, SimpleMesh.h:60-68.
+void rt_mesh_normalize(rt_mesh* mesh)
+{
+    if (!mesh || mesh->vertices.empty()) return;
+    Vec3 c; float r; center_and_radius(mesh, c, r);
+    for (auto& v : mesh->vertices) store3(v.position, (load3(v.position) - c) / r);
+}
+
+// SimpleMesh::resize, SimpleMesh.h:79-85: scales all four position components.
+void rt_mesh_resize(rt_mesh* mesh)
+{
+    if (!mesh) return;
+    const float factor = 2;
+    for (auto& v : mesh->vertices) for (int k = 0; k < 4; ++k) v.position[k] *= factor;
+}
+
+// SimpleMesh::transform, SimpleMesh.h:122-126.
+void rt_mesh_transform(rt_mesh* mesh, const float rot[9], const float translation[3])
+{
+    if (!mesh) return;
+    Mat3 r; memcpy(r.m, rot, sizeof r.m);
+    for (auto& v : mesh->vertices) store3(v.position, mul(r, load3(v.position)) + load3(translation));
+}
+
+void rt_mesh_copy_vertices(const rt_mesh* mesh, float* positions, float* colors)
+{
+    if (!mesh) return;
+    for (size_t i = 0; i < mesh->vertices.size(); ++i) {
+        if (positions) memcpy(positions + 4 * i, mesh->vertices[i].position, 16);
+        if (colors) memcpy(colors + 4 * i, mesh->vertices[i].color, 16);
+    }
+}
+
+void rt_mesh_copy_indices(const rt_mesh* mesh, uint32_t* indices)
+{
+    if (mesh && indices && !mesh->indices.empty()) memcpy(indices, mesh->indices.data(), mesh->indices.size() * sizeof(uint32_t));
+}
+
+// The loop of src/main.cpp:113-122.
+void rt_mesh_to_triangles(const rt_mesh* mesh, rt_triangle* out)
+{
+    if (!mesh || !out) return;
+    for (size_t t = 0; t < mesh->indices.size() / 3; ++t) {
+        const float* v0 = mesh->vertices[mesh->indices[3 * t]].position;
+        const float* v1 = mesh->vertices[mesh->indices[3 * t + 1]].position;
+        const float* v2 = mesh->vertices[mesh->indices[3 * t + 2]].position;
+        rt_make_triangle(&out[t], v0, v1, v2);
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,304 @@
+"""Host-side mirror of the reference's scene and render-call classes.
+
+Same names and argument meaning as the reference's C++ headers
+(src/gpu_version/shape.h, camera.h, ray_tracing_compute_shader.h,
+src/SimpleMesh.h), so that code and tests read like src/main.cpp:88-151.  All
+arithmetic and all rendering happen in librt_mi355x.so; this module only
+marshals.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import (MATERIAL_DTYPE, SHAPE_DTYPE, TRIANGLE_DTYPE, RtError, lib,
+                   SEM_CPU, SEM_GLSL, SAMPLE_JITTER)
+
+
+# ---------------------------------------------------------------- materials
+# src/gpu_version/shape.h:5-42
+class Material:
+    def __init__(self, type_, color, data=(0.0, 0.0, 0.0, 0.0)):
+        self.rec = np.zeros((), dtype=MATERIAL_DTYPE)
+        self.rec["color"] = np.asarray(color, dtype=np.float32)
+        self.rec["type"] = type_
+        self.rec["data"] = np.asarray(data, dtype=np.float32)
+
+    @property
+    def type(self):
+        return int(self.rec["type"])
+
+    @property
+    def color(self):
+        return self.rec["color"]
+
+
+class Light(Material):                      # shape.h:14-19
+    def __init__(self, color):
+        super().__init__(_abi.MAT_LIGHT, color)
+
+
+class Lambertian(Material):                 # shape.h:21-26
+    def __init__(self, color):
+        super().__init__(_abi.MAT_LAMBERTIAN, color)
+
+
+class Metal(Material):                      # shape.h:28-34; fuzz: src/cpu_version/scene.h:71
+    def __init__(self, color, refraction=1.0, fuzz=0.0):
+        super().__init__(_abi.MAT_METAL, color, (refraction, fuzz, 0.0, 0.0))
+
+
+class DebugMaterial(Material):              # shape.h:37-42
+    def __init__(self, color):
+        super().__init__(_abi.MAT_DEBUG, color)
+
+
+# ------------------------------------------------------------------- shapes
+# src/gpu_version/shape.h:44-70
+class Shape:
+    def __init__(self):
+        self.rec = np.zeros((), dtype=SHAPE_DTYPE)
+
+    @property
+    def transformation(self):
+        """4x4, element [r][c] (stored column-major like Eigen's ColMajor)."""
+        return self.rec["transformation"].reshape(4, 4).T
+
+
+class Circle(Shape):                        # shape.h:56-62
+    def __init__(self, translation, radius, material):
+        super().__init__()
+        lib.rt_make_circle(self.rec.ctypes.data, _abi.f3(translation), float(radius), material.rec.ctypes.data)
+
+
+class Box(Shape):                           # shape.h:64-70
+    def __init__(self, translation, sides, material):
+        super().__init__()
+        lib.rt_make_box(self.rec.ctypes.data, _abi.f3(translation), _abi.f3(sides), material.rec.ctypes.data)
+
+
+class SimpleTriangle:                       # shape.h:81-109
+    def __init__(self, p1, p2, p3):
+        self.rec = np.zeros((), dtype=TRIANGLE_DTYPE)
+        lib.rt_make_triangle(self.rec.ctypes.data, _abi.f3(p1), _abi.f3(p2), _abi.f3(p3))
+
+
+def pack(records, dtype):
+    """list of objects with .rec (or a ready structured array) -> contiguous array."""
+    if isinstance(records, np.ndarray):
+        assert records.dtype == dtype
+        return np.ascontiguousarray(records)
+    out = np.zeros(len(records), dtype=dtype)
+    for i, r in enumerate(records):
+        out[i] = r.rec
+    return out
+
+
+# ------------------------------------------------------------------- camera
+class Camera:
+    """src/gpu_version/camera.h:8-122.  `position` defaults to the GPU host's
+    (1,1,6) (camera.h:17); the CPU tracer uses (1,0,6) (rayTracer.h:37)."""
+
+    FORWARD, BACKWARD, RIGHT, LEFT = 0, 1, 2, 3       # camera.h:10-12
+    dataSize = _abi.RT_CAMERA_FLOATS
+
+    def __init__(self, width, height, focalLength=1.0, position=(1.0, 1.0, 6.0)):
+        self.width, self.height, self.focalLength = int(width), int(height), float(focalLength)
+        self.data = np.zeros(self.dataSize, dtype=np.float32)
+        lib.rt_camera_init(_abi.fptr(self.data), self.width, self.height, self.focalLength, _abi.f3(position))
+
+    def getCameraPosition(self):
+        return self.data[0:3]
+
+    def getCameraDirection(self):
+        return self.data[4:7]
+
+    def getUpperLeft(self):
+        return self.data[8:11]
+
+    def getUpDirection(self):
+        return self.data[12:15]
+
+    def getRightDirection(self):
+        return self.data[16:19]
+
+    def getWorldStep(self):
+        return float(self.data[19])
+
+    def rotate(self, horizontal, vertical):             # camera.h:85-92
+        lib.rt_camera_rotate(_abi.fptr(self.data), self.width, self.height, self.focalLength,
+                             float(horizontal), float(vertical))
+
+    def move(self, direction):                          # camera.h:94-113
+        lib.rt_camera_move(_abi.fptr(self.data), self.width, self.height, self.focalLength, int(direction))
+
+
+# --------------------------------------------------------------------- mesh
+class SimpleMesh:
+    """src/SimpleMesh.h:22-323 (loadMesh, normalize, resize, transform)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.rt_mesh_free(self._h)
+            self._h = C.c_void_p()
+
+    def loadMesh(self, filename):                       # SimpleMesh.h:145-215
+        if self._h:
+            lib.rt_mesh_free(self._h)
+            self._h = C.c_void_p()
+        rc = lib.rt_mesh_load(C.byref(self._h), str(filename).encode())
+        return rc == 0
+
+    def normalize(self):                                # SimpleMesh.h:60-68
+        lib.rt_mesh_normalize(self._h)
+
+    def resize(self):                                   # SimpleMesh.h:79-85
+        lib.rt_mesh_resize(self._h)
+
+    def transform(self, rotation, translation):         # SimpleMesh.h:122-126
+        r = np.ascontiguousarray(np.asarray(rotation, dtype=np.float32).reshape(3, 3))
+        lib.rt_mesh_transform(self._h, _abi.fptr(r), _abi.f3(translation))
+
+    def getVertices(self):
+        """(positions[n,4], colors[n,4])"""
+        n = lib.rt_mesh_vertex_count(self._h)
+        pos = np.zeros((n, 4), dtype=np.float32)
+        col = np.zeros((n, 4), dtype=np.float32)
+        lib.rt_mesh_copy_vertices(self._h, pos.ctypes.data, col.ctypes.data)
+        return pos, col
+
+    def getTriangles(self):
+        n = lib.rt_mesh_triangle_count(self._h)
+        idx = np.zeros((n, 3), dtype=np.uint32)
+        lib.rt_mesh_copy_indices(self._h, idx.ctypes.data)
+        return idx
+
+    def toSimpleTriangles(self):
+        """The loop of src/main.cpp:113-122 -> structured array of SimpleTriangle."""
+        n = lib.rt_mesh_triangle_count(self._h)
+        out = np.zeros(n, dtype=TRIANGLE_DTYPE)
+        lib.rt_mesh_to_triangles(self._h, out.ctypes.data)
+        return out
+
+
+# ------------------------------------------------------ render-call surface
+class RayTracingComputeShader:
+    """src/gpu_version/ray_tracing_compute_shader.h:9-67 on top of the HIP core.
+
+    `shapes` / `triangles` are public lists filled by the caller and uploaded
+    by updateShapeBuffer(), exactly as in src/main.cpp:95-124.  compute(x,y,z)
+    is the dispatch of main.cpp:145; the wall-clock `time` uniform of
+    main.cpp:139-141 becomes the explicit `seed`.
+    """
+
+    def __init__(self, camera, device=0, semantics=SEM_GLSL, sample_mode=SAMPLE_JITTER, flags=0,
+                 triangle_albedo=(1.0, 0.0, 0.0), samples_per_frame=100, max_depth=10, seed=1):
+        self.camera = camera
+        self.shapes = []
+        self.triangles = []
+        self.semantics = semantics
+        self.samples_per_frame = samples_per_frame      # RayTracing.glsl:2,6 (10 x 10)
+        self.max_depth = max_depth                      # RayTracing.glsl:300
+        self.seed = seed
+        self.frame = 0
+        self.grid_n = 0
+        cfg = _abi.Config(C.sizeof(_abi.Config), device, semantics, sample_mode, flags,
+                          (C.c_float * 3)(*triangle_albedo))
+        self._ctx = C.c_void_p()
+        rc = lib.rt_create(C.byref(self._ctx), C.byref(cfg))
+        if rc != 0:
+            raise RtError(rc, lib.rt_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            lib.rt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RtError(rc, lib.rt_last_error(self._ctx).decode())
+
+    # -- reference surface ------------------------------------------------
+    def updateCameraBuffer(self):                        # :34-37
+        self._check(lib.rt_set_camera(self._ctx, _abi.fptr(self.camera.data)))
+
+    def updateShapeBuffer(self):                         # :44-57
+        s = pack(self.shapes, SHAPE_DTYPE)
+        t = pack(self.triangles, TRIANGLE_DTYPE)
+        self._check(lib.rt_upload_shapes(self._ctx, s.ctypes.data if len(s) else None, len(s)))
+        self._check(lib.rt_upload_triangles(self._ctx, t.ctypes.data if len(t) else None, len(t)))
+
+    def compute(self, x, y, z=1, spp=None, first_sample=None):   # :39-42
+        """One dispatch over x * y pixels: samples_per_frame new samples per pixel."""
+        assert z == 1
+        spp = self.samples_per_frame if spp is None else spp
+        first = self.frame * self.samples_per_frame if first_sample is None else first_sample
+        self._check(lib.rt_render(self._ctx, x, y, spp, self.max_depth, self.seed, first, self.grid_n))
+        self.frame += 1
+
+    def convert(self, n_samples):                        # main.cpp:147-151 + PixelConversion.glsl
+        self._check(lib.rt_convert(self._ctx, n_samples))
+
+    def readImage(self):
+        w, h = self.camera.width, self.camera.height
+        out = np.zeros((h, w, 4), dtype=np.float32)
+        self._check(lib.rt_read_image(self._ctx, out.ctypes.data))
+        return out
+
+    # -- extras of the C ABI ---------------------------------------------
+    def setStream(self, stream_ptr):
+        self._check(lib.rt_set_stream(self._ctx, C.c_void_p(stream_ptr)))
+
+    def setRowShard(self, index, count, band_rows=16):
+        self._check(lib.rt_set_row_shard(self._ctx, index, count, band_rows))
+
+    def bindAccum(self, device_ptr, width, height):
+        self._check(lib.rt_bind_accum(self._ctx, C.c_void_p(device_ptr) if device_ptr else None, width, height))
+
+    def render(self, width, height, spp, max_depth, seed, first_sample=0, grid_n=0, stats=False):
+        if stats:
+            st = _abi.Stats()
+            self._check(lib.rt_render_stats(self._ctx, width, height, spp, max_depth, seed, first_sample, grid_n,
+                                            C.byref(st)))
+            return st.as_dict()
+        self._check(lib.rt_render(self._ctx, width, height, spp, max_depth, seed, first_sample, grid_n))
+        return None
+
+    def resetAccum(self):
+        self._check(lib.rt_reset_accum(self._ctx))
+        self.frame = 0
+
+    def accumSamples(self):
+        n = C.c_uint32()
+        self._check(lib.rt_accum_samples(self._ctx, C.byref(n)))
+        return n.value
+
+    def resolve(self, width, height, gamma_sqrt=False, flip_rows=True):
+        out = np.zeros((height, width, 4), dtype=np.float32)
+        self._check(lib.rt_resolve(self._ctx, out.ctypes.data, int(gamma_sqrt), int(flip_rows)))
+        return out
+
+    def resolveDevice(self, device_ptr, gamma_sqrt=False, flip_rows=True):
+        self._check(lib.rt_resolve_device(self._ctx, C.c_void_p(device_ptr), int(gamma_sqrt), int(flip_rows)))
+
+    def traceDebug(self, width, height, max_depth, seed, sample, grid_n=0):
+        hit = np.zeros((height, width, max_depth), dtype=np.int32)
+        mat = np.zeros((height, width, max_depth), dtype=np.uint32)
+        self._check(lib.rt_trace_debug(self._ctx, width, height, max_depth, seed, sample, grid_n,
+                                       hit.ctypes.data, mat.ctypes.data))
+        return hit, mat
+
+
+def device_info(device=0):
+    name = C.create_string_buffer(256)
+    cu, mhz = C.c_int(), C.c_int()
+    rc = lib.rt_device_info(device, name, 256, C.byref(cu), C.byref(mhz))
+    if rc != 0:
+        raise RtError(rc, "no HIP device")
+    return {"name": name.value.decode(), "compute_units": cu.value, "clock_mhz": mhz.value}

@@ -1,0 +1,221 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on the same scenes and seeds.
+
+Bar: bit-exact.  The kernels use only IEEE-754 binary32 +,-,*,/,sqrt and explicit fma in a fixed order,
+so hit indices, material ids, work counters AND every accumulated pixel word must equal the oracle's.
+(Against the reference's own product order — the recursion of rayTracer.h:121 — colours agree to
+rounding: rtol 2e-6, checked on the oracle side in test_oracle_kat.py.)
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+COUNTERS = ("samples", "segments", "diffuse", "specular", "terminal",
+            "shape_tests", "sphere_tests", "box_tests", "triangle_tests")
+
+
+def oracle_params(orc, cfg, **kw):
+    args = dict(seed=cfg.seed, semantics=cfg.semantics, sample_mode=cfg.sample_mode, flags=cfg.flags,
+                triangle_albedo=cfg.triangle_albedo)
+    args.update(kw)
+    return orc.params(cfg.width, cfg.height, cfg.spp, cfg.max_depth, **args)
+
+
+def check_config(rta, orc, cfg, trace_samples=(0,), grid_n=0):
+    rt = rta.scenes.make_renderer(cfg)
+    try:
+        stats = rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, grid_n=grid_n, stats=True)
+        img = rt.resolve(cfg.width, cfg.height, gamma_sqrt=(cfg.semantics == 0))
+        p = oracle_params(orc, cfg, grid_n=grid_n)
+        acc, ostats = orc.render(cfg.shapes, cfg.triangles, cfg.camera, p)
+        ref = orc.resolve(acc, cfg.spp, cfg.semantics, gamma_sqrt=(cfg.semantics == 0))
+        assert {k: stats[k] for k in COUNTERS} == {k: ostats[k] for k in COUNTERS}
+        diff = img.view(np.uint32) != ref.view(np.uint32)
+        assert not diff.any(), f"{int(diff.sum())} of {diff.size} image words differ from the oracle"
+        assert ref[..., :3].max() > 0
+        for s in trace_samples:
+            hit, mat = rt.traceDebug(cfg.width, cfg.height, cfg.max_depth, cfg.seed, s, grid_n=grid_n)
+            ohit, omat = orc.trace(cfg.shapes, cfg.triangles, cfg.camera, p, s)
+            np.testing.assert_array_equal(hit, ohit)
+            np.testing.assert_array_equal(mat, omat)
+        # the plain render (no counters) gives the same words
+        rt.resetAccum()
+        rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, grid_n=grid_n)
+        img2 = rt.resolve(cfg.width, cfg.height, gamma_sqrt=(cfg.semantics == 0))
+        np.testing.assert_array_equal(img2.view(np.uint32), img.view(np.uint32))
+    finally:
+        rt.close()
+    return stats
+
+
+def test_config1_cpu_sphere_scene(rta, orc):
+    """BASELINE config 1 at full size: 512x512, 16 spp, depth 4."""
+    st = check_config(rta, orc, rta.scenes.config1(), trace_samples=(0, 7, 15))
+    assert st["samples"] == 512 * 512 * 16
+
+
+def test_config2_scene_reduced(rta, orc):
+    """Config 2's scene and depth at 320x180 (the oracle finishes in seconds), ragged tile edges."""
+    check_config(rta, orc, rta.scenes.config2(width=323, height=181, spp=25, max_depth=8), trace_samples=(0, 24))
+
+
+def test_config3_mesh_scene(rta, orc):
+    """main.cpp's shapes + the 292-triangle bunny, shader semantics (boxes, mirror, quantised sums)."""
+    check_config(rta, orc, rta.scenes.config3(width=160, height=90, spp=8, max_depth=10), trace_samples=(0, 5))
+
+
+def test_config3_big_bunny(rta, orc):
+    """The 4 968-triangle COFF bunny."""
+    check_config(rta, orc, rta.scenes.config3(width=64, height=36, spp=2, max_depth=6, mesh="bunny.off"))
+
+
+def test_config4_multi_light_metal(rta, orc):
+    """Fuzzy metal (scene.h:73-81) + several emitters under the CPU tracer's rules."""
+    check_config(rta, orc, rta.scenes.config4(width=192, height=108, spp=16, max_depth=11), trace_samples=(0, 9))
+
+
+def test_config5_divergence_scene(rta, orc):
+    check_config(rta, orc, rta.scenes.config5(width=128, height=128, spp=8, max_depth=16), trace_samples=(3,))
+
+
+def test_metal_unnormalized_flag(rta, orc):
+    cfg = rta.scenes.config4(width=96, height=54, spp=8, max_depth=11)
+    cfg.flags = rta.FLAG_METAL_UNNORMALIZED
+    check_config(rta, orc, cfg)
+
+
+@pytest.mark.parametrize("mode", ["grid", "grid_compat"])
+def test_grid_sample_modes(rta, orc, mode):
+    """renderPixel<N> of rayTracer.h:89-108 (N = 5 as in rayTracer.h:78)."""
+    cfg = rta.scenes.config1(width=96, height=64, spp=25, max_depth=11)
+    cfg.sample_mode = rta.SAMPLE_GRID if mode == "grid" else rta.SAMPLE_GRID_COMPAT
+    check_config(rta, orc, cfg, trace_samples=(0, 13, 24), grid_n=5)
+
+
+def test_cpu_semantics_with_triangles_and_boxes(rta, orc):
+    """CPU-tracer shading rules over the shader's box and triangle geometry (mixed scene)."""
+    cfg = rta.scenes.config3(width=96, height=54, spp=4, max_depth=8)
+    cfg.semantics = rta.SEM_CPU
+    cfg.triangle_albedo = (0.9, 0.4, 0.1)
+    check_config(rta, orc, cfg)
+
+
+def test_glsl_semantics_on_sphere_scene_with_debug_material(rta, orc):
+    cfg = rta.scenes.config1(width=80, height=60, spp=4, max_depth=10)
+    cfg.semantics = rta.SEM_GLSL
+    cfg.shapes = cfg.shapes.copy()
+    cfg.shapes["material"]["type"][1] = 100           # DebugMaterial: normal as colour (shape.h:37-42)
+    cfg.shapes["material"]["type"][0] = 55            # unknown type: returns the throughput (glsl:253)
+    check_config(rta, orc, cfg, trace_samples=(1,))
+
+
+def test_empty_scene_and_single_pixel(rta, orc):
+    cfg = rta.scenes.config1(width=1, height=1, spp=3, max_depth=2)
+    rt = rta.scenes.make_renderer(cfg)
+    rt.render(1, 1, 3, 2, 1)
+    acc, _ = orc.render(cfg.shapes, cfg.triangles, cfg.camera, oracle_params(orc, cfg))
+    np.testing.assert_array_equal(rt.resolve(1, 1).view(np.uint32), orc.resolve(acc, 3, 0).view(np.uint32))
+    rt.shapes = np.zeros(0, rta.SHAPE_DTYPE)
+    rt.updateShapeBuffer()
+    rt.resetAccum()
+    st = rt.render(1, 1, 3, 2, 1, stats=True)
+    assert st["segments"] == 3 and not rt.resolve(1, 1)[..., :3].any()
+    rt.close()
+
+
+def test_progressive_chunks_equal_one_shot(rta, orc):
+    """Sums continue across render calls in sample order: 4+4+8 samples == 16 at once, bit for bit."""
+    cfg = rta.scenes.config1(width=128, height=72, spp=16, max_depth=6)
+    rt = rta.scenes.make_renderer(cfg)
+    rt.render(128, 72, 16, 6, 5)
+    one = rt.resolve(128, 72)
+    rt.resetAccum()
+    for first, n in ((0, 4), (4, 4), (8, 8)):
+        rt.render(128, 72, n, 6, 5, first_sample=first)
+    assert rt.accumSamples() == 16
+    np.testing.assert_array_equal(rt.resolve(128, 72).view(np.uint32), one.view(np.uint32))
+    rt.close()
+
+
+def test_row_shards_reassemble_bit_exact(rta, orc):
+    """What each GPU of a node renders (rows with (y//16) % G == g): the shards sum to the whole frame."""
+    import torch
+    cfg = rta.scenes.config2(width=200, height=150, spp=6, max_depth=8)
+    rt = rta.scenes.make_renderer(cfg)
+    rt.render(200, 150, 6, 8, 1)
+    whole = rt.resolve(200, 150)
+    total = torch.zeros(150, 200, 4, dtype=torch.float32, device="cuda")
+    for g in range(3):
+        part = torch.zeros(150, 200, 4, dtype=torch.int32, device="cuda")
+        rt.bindAccum(part.data_ptr(), 200, 150)
+        rt.setRowShard(g, 3, 16)
+        rt.render(200, 150, 6, 8, 1)
+        torch.cuda.synchronize()
+        rows = torch.tensor([(y // 16) % 3 == g for y in range(150)], device="cuda")
+        assert not part[~rows].any()
+        total += part.view(torch.float32)
+    rt.bindAccum(None, 0, 0)
+    rt.close()
+    ref = (total[..., :3] / 6).cpu().numpy()[::-1]
+    np.testing.assert_array_equal(ref.view(np.uint32), whole[..., :3].copy().view(np.uint32))
+
+
+def test_converter_running_mean(rta, orc):
+    """main.cpp:135-151 for three frames against the oracle's PixelConversion restatement."""
+    cfg = rta.scenes.config3(width=96, height=54, spp=10, max_depth=10)
+    rt = rta.scenes.make_renderer(cfg)
+    image = np.zeros((54, 96, 4), np.float32)
+    for n in (1, 2, 3):
+        rt.updateCameraBuffer()                       # main.cpp:143
+        rt.compute(96, 54, 1)                         # main.cpp:145
+        rt.convert(n)                                 # main.cpp:147-149
+        p = oracle_params(orc, cfg, first_sample=(n - 1) * 10)
+        acc, _ = orc.render(cfg.shapes, cfg.triangles, cfg.camera, p)
+        orc.convert(acc, image, 10, cfg.semantics, n)
+    np.testing.assert_array_equal(rt.readImage().view(np.uint32), image.view(np.uint32))
+    rt.close()
+
+
+def test_full_size_properties(rta):
+    """Config 2 at full size (1920x1080, 100 spp, depth 8): properties that need no oracle run."""
+    cfg = rta.scenes.config2()
+    rt = rta.scenes.make_renderer(cfg)
+    st = rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, stats=True)
+    img = rt.resolve(cfg.width, cfg.height)
+    assert st["samples"] == 1920 * 1080 * 100 and st["terminal"] == st["samples"]
+    assert st["samples"] <= st["segments"] <= 8 * st["samples"]
+    assert np.isfinite(img).all() and img[..., :3].min() >= 0 and img[..., :3].max() <= 5.0
+    # idempotence: the same call again gives the same words
+    rt.resetAccum()
+    rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed)
+    np.testing.assert_array_equal(rt.resolve(cfg.width, cfg.height).view(np.uint32), img.view(np.uint32))
+    # linearity in the sample split: 60 + 40 samples == 100
+    rt.resetAccum()
+    rt.render(cfg.width, cfg.height, 60, cfg.max_depth, cfg.seed, first_sample=0)
+    rt.render(cfg.width, cfg.height, 40, cfg.max_depth, cfg.seed, first_sample=60)
+    np.testing.assert_array_equal(rt.resolve(cfg.width, cfg.height).view(np.uint32), img.view(np.uint32))
+    # a different seed gives a different image with the same mean to Monte-Carlo accuracy
+    rt.resetAccum()
+    rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed + 1)
+    img2 = rt.resolve(cfg.width, cfg.height)
+    assert (img2 != img).any() and abs(img2[..., :3].mean() - img[..., :3].mean()) < 0.01 * img[..., :3].mean()
+    rt.close()
+
+
+def test_argument_errors(rta):
+    cfg = rta.scenes.config1(width=32, height=32, spp=1, max_depth=2)
+    rt = rta.scenes.make_renderer(cfg)
+    with pytest.raises(rta.RtError):
+        rt.render(0, 32, 1, 2, 1)
+    with pytest.raises(rta.RtError):
+        rt.render(32, 32, 1, 0, 1)
+    with pytest.raises(rta.RtError):
+        rt.resolve(32, 32)                 # nothing rendered yet
+    with pytest.raises(rta.RtError):
+        rt.setRowShard(3, 3)
+    rt.close()
+    cam = rta.Camera(8, 8)
+    rt2 = rta.RayTracingComputeShader(cam)
+    with pytest.raises(rta.RtError):
+        rt2.render(8, 8, 1, 2, 1)          # camera never set
+    rt2.close()

@@ -1,0 +1,282 @@
+"""Known-answer tests that pin the CPU oracle: closed forms for every routine it restates.
+The reference holds no golden vectors, so these (plus tests/golden) are what the oracle stands on."""
+import math
+
+import numpy as np
+import pytest
+
+
+def lowbias32(x):
+    x &= 0xffffffff
+    x ^= x >> 16; x = (x * 0x7feb352d) & 0xffffffff
+    x ^= x >> 15; x = (x * 0x846ca68b) & 0xffffffff
+    x ^= x >> 16
+    return x
+
+
+def test_hash_and_draws(orc):
+    for x in (0, 1, 2, 0xdeadbeef, 0xffffffff, 12345):
+        assert orc.lib.orc_hash32(x) == lowbias32(x)
+    key = orc.lib.orc_path_key(1, 77, 3)
+    sk = lowbias32((1 & 0xffffffff) ^ lowbias32(0 ^ 0x85ebca6b))
+    assert key == lowbias32(lowbias32(sk ^ 77) ^ 3)
+    for i in range(16):
+        u = orc.lib.orc_draw(key, i)
+        assert u == (lowbias32((key + i * 0x9e3779b9) & 0xffffffff) >> 8) / 2 ** 24
+        assert 0.0 <= u < 1.0
+    us = np.array([orc.lib.orc_draw(lowbias32(k), i) for k in range(200) for i in range(50)])
+    assert abs(us.mean() - 0.5) < 0.01 and abs(us.var() - 1 / 12) < 0.005
+    # streams of neighbouring pixels / samples are different
+    assert len({orc.lib.orc_path_key(1, p, s) for p in range(64) for s in range(64)}) == 4096
+
+
+def test_sincos2pi(orc):
+    assert orc.sincos2pi(0.0) == (1.0, 0.0)
+    c, s = orc.sincos2pi(0.25); assert abs(c) < 1e-7 and abs(s - 1) < 1e-7 and c == -0.0 or c == 0.0
+    assert orc.sincos2pi(0.5) == (-1.0, -0.0)
+    c, s = orc.sincos2pi(0.75); assert c == 0.0 and s == -1.0
+    us = (np.arange(0, 1 << 24, 4099, dtype=np.int64) / 2.0 ** 24).astype(np.float32)
+    err = 0.0
+    for u in us:
+        c, s = orc.sincos2pi(float(u))
+        err = max(err, abs(c - math.cos(2 * math.pi * float(u))), abs(s - math.sin(2 * math.pi * float(u))))
+    assert err < 2.5e-7
+
+
+def test_unit_vector_is_uniform_on_the_sphere(orc):
+    rng = np.random.RandomState(1)
+    u = (rng.randint(0, 1 << 24, (4000, 2)) / 2.0 ** 24).astype(np.float32)
+    v = np.array([orc.unit_vector(float(a), float(b)) for a, b in u], dtype=np.float64)
+    assert np.abs(np.linalg.norm(v, axis=1) - 1).max() < 3e-7
+    assert np.abs(v.mean(0)).max() < 0.04                    # E[v] = 0
+    np.testing.assert_allclose((v ** 2).mean(0), [1 / 3] * 3, atol=0.02)   # E[v_i^2] = 1/3
+    np.testing.assert_array_equal(orc.unit_vector(0.0, 0.0), [0, 0, 1])   # z = 1 - 2*u1
+    assert orc.unit_vector(0.5, 0.0)[2] == 0.0
+
+
+def test_hemisphere_glsl(orc):
+    rng = np.random.RandomState(2)
+    for n in ([0, 1, 0], [0, 0, 1], [0, 0, -1], [1, 0, 0], [0.6, 0.0, 0.8], [0.001, 0.002, 0.999997]):
+        n = np.array(n, dtype=np.float32); n /= np.float32(np.linalg.norm(n))
+        for _ in range(100):
+            u1, u2 = (rng.randint(0, 1 << 24, 2) / 2.0 ** 24).astype(np.float32)
+            d = orc.hemisphere_glsl(n, float(u1), float(u2)).astype(np.float64)
+            assert abs(np.linalg.norm(d) - 1) < 2e-6
+            assert abs(d @ n - u2) < 2e-6                 # RayTracing.glsl:78: component along n is r = u2
+    # n = +-z takes the fallback tangent of RayTracing.glsl:72-73
+    d = orc.hemisphere_glsl([0, 0, 1], 0.0, 0.0)
+    np.testing.assert_allclose(d, [0, -1, 0], atol=1e-7)
+
+
+def test_hit_sphere_closed_forms(orc):
+    inf = float("inf")
+    assert orc.hit_sphere((0, 0, 0), 1.0, (0, 0, 5), (0, 0, -1)) == 4.0        # head-on, near root
+    assert orc.hit_sphere((0, 0, 0), 1.0, (0, 0, 5), (0, 0, 1)) == -6.0        # behind: -b - sqrt(disc) < 0
+    assert orc.hit_sphere((0, 0, 0), 1.0, (0, 2, 5), (0, 0, -1)) == inf        # miss
+    assert orc.hit_sphere((0, 0, 0), 1.0, (0, 1, 5), (0, 0, -1)) == 5.0        # tangent: disc = 0
+    assert orc.hit_sphere((0, 0, 0), 1.0, (0, 0, 0), (0, 0, -1)) == -1.0       # from inside: near root is behind
+    assert orc.hit_sphere((1, 2, -2), 0.5, (1, 2, 6), (0, 0, -1)) == 7.5
+    d = np.array([3, 4, 12], dtype=np.float64) / 13
+    t = orc.hit_sphere((3, 4, 12), 2.0, (0, 0, 0), tuple(d))
+    assert abs(t - 11.0) < 1e-5
+
+
+def test_hit_box_closed_forms(orc):
+    inf = float("inf")
+    assert orc.hit_box((0, 0, 0), 2.0, (0.25, 0.5, 5), (0, 0, -1)) == 4.0
+    assert orc.hit_box((0, 0, 0), 2.0, (5, 0.25, 0.5), (-1, 0, 0)) == 4.0
+    assert orc.hit_box((0, 0, 0), 2.0, (0.25, -5, 0.5), (0, 1, 0)) == 4.0
+    assert orc.hit_box((0, 0, 0), 2.0, (3, 0.5, 5), (0, 0, -1)) == inf          # passes beside
+    assert orc.hit_box((1, 1, 1), 1.0, (1.25, 1.1, 4), (0, 0, -1)) == 2.5
+    # sign(0) = 0 -> 0/0 -> NaN -> rejected (RayTracing.glsl:144-145): an origin component exactly 0
+    # still hits through the other axes
+    assert orc.hit_box((0, 0, 0), 2.0, (0, 0.5, 5), (0, 0, -1)) == 4.0
+    np.testing.assert_array_equal(orc.box_normal((0, 0, 0), 2.0, (0.3, 0.2, 1.0)), [0, 0, 1])
+    np.testing.assert_array_equal(orc.box_normal((0, 0, 0), 2.0, (-1.0, 0.2, 0.1)), [-1, 0, 0])
+    np.testing.assert_allclose(orc.box_normal((0, 0, 0), 2.0, (1.0, 1.0, 0.1)), [2 ** -0.5, 2 ** -0.5, 0], atol=1e-7)
+    # only transformation[0][0] scales the box (RayTracing.glsl:139): Box({..},{10,1,1}) is a 10-cube
+    assert abs(orc.hit_box((-1, 12, -2), 10.0, (-1, 0, -2.5), (0, 1, 0)) - 7.0) < 1e-5
+
+
+def test_hit_triangle_closed_forms(orc):
+    inf = float("inf")
+    t = orc.make_triangle((0, 0, 0), (1, 0, 0), (0, 1, 0))
+    assert orc.hit_triangle(t, (0.25, 0.25, 3), (0, 0, -1)) == 3.0
+    assert orc.hit_triangle(t, (0.25, 0.25, -3), (0, 0, 1)) == 3.0             # two-sided
+    assert orc.hit_triangle(t, (0.75, 0.75, 3), (0, 0, -1)) == inf             # x + y >= 1
+    assert orc.hit_triangle(t, (-0.1, 0.25, 3), (0, 0, -1)) == inf
+    assert orc.hit_triangle(t, (0.25, 0.25, 3), (0, 0, 1)) == inf              # k < 0
+    assert orc.hit_triangle(t, (0.25, 0.25, 3), (1, 0, 0)) == inf              # parallel: k = inf or nan
+    rng = np.random.RandomState(5)
+    for _ in range(100):
+        p = rng.uniform(-1, 1, (3, 3)).astype(np.float32)
+        tri = orc.make_triangle(*p)
+        bary = rng.dirichlet([1, 1, 1])
+        target = (bary[:, None] * p.astype(np.float64)).sum(0)
+        o = target + rng.uniform(-1, 1, 3) + np.array([0, 0, 4])
+        d = target - o; dist = np.linalg.norm(d); d /= dist
+        got = orc.hit_triangle(tri, tuple(o.astype(np.float32)), tuple(d.astype(np.float32)))
+        if bary.min() > 0.02:
+            assert abs(got - dist) < 1e-3 * dist
+
+
+def test_camera_rays(rta, orc):
+    cam = rta.Camera(64, 36, 1.0, (1, 0, 6)).data
+    step = float(cam[19])
+    ul = cam[8:11].astype(np.float64)
+    # jitter (RayTracing.glsl:296): origin inside the pixel, on the image plane, unit direction
+    p = orc.params(64, 36, 4, 4, seed=9)
+    for gx, gy, s in [(0, 0, 0), (63, 35, 3), (10, 20, 1)]:
+        o, d = orc.camera_ray(cam, p, gx, gy, s)
+        assert ul[0] + step * gx <= o[0] < ul[0] + step * (gx + 1) + 1e-6
+        assert ul[1] - step * (gy + 1) - 1e-6 < o[1] <= ul[1] - step * gy
+        assert o[2] == cam[10]
+        assert abs(np.linalg.norm(d.astype(np.float64)) - 1) < 2e-7
+        w = o.astype(np.float64) - cam[0:3]
+        np.testing.assert_allclose(d, w / np.linalg.norm(w), atol=2e-7)
+    # regular grid: offsets (j, -i) * step/(N+1)
+    p = orc.params(64, 36, 16, 4, sample_mode=orc.SAMPLE_GRID)
+    o00, _ = orc.camera_ray(cam, p, 5, 7, 0)
+    np.testing.assert_allclose(o00, [ul[0] + 5 * step, ul[1] - 7 * step, ul[2]], atol=1e-6)
+    for s in range(16):
+        i, j = s // 4, s % 4
+        o, _ = orc.camera_ray(cam, p, 5, 7, s)
+        np.testing.assert_allclose(o - o00, [j * step / 5, -i * step / 5, 0], atol=1e-7)
+    # rayTracer.h:98-99 as written: the x offset accumulates 0, 1, 3, 6 (x step/(N+1))
+    p = orc.params(64, 36, 16, 4, sample_mode=orc.SAMPLE_GRID_COMPAT)
+    for s in range(16):
+        i, j = s // 4, s % 4
+        o, _ = orc.camera_ray(cam, p, 5, 7, s)
+        np.testing.assert_allclose(o - o00, [j * (j + 1) / 2 * step / 5, -i * step / 5, 0], atol=1e-7)
+
+
+def one_light_scene(rta):
+    return rta.pack([rta.Circle((1, 0, -2), 1.0, rta.Light((5, 4, 3)))], rta.SHAPE_DTYPE)
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+def test_direct_light_image(rta, orc, sem):
+    """A lone emitter: pixels whose ray hits it get its colour, all others are black."""
+    shapes = one_light_scene(rta)
+    cam = rta.Camera(64, 64, 1.0, (1, 0, 6)).data
+    p = orc.params(64, 64, 4, 3, semantics=sem)
+    acc, st = orc.render(shapes, np.zeros(0, rta.TRIANGLE_DTYPE), cam, p)
+    img = orc.resolve(acc, 4, sem, flip_rows=False)
+    hit, mat = orc.trace(shapes, np.zeros(0, rta.TRIANGLE_DTYPE), cam, p, 0)
+    lit = hit[:, :, 0] == 0
+    # projected disc: tan(angle) = 1/sqrt(8^2-1); image plane at distance 1, pixel = 1/64
+    r_pix = 64 / math.sqrt(63)
+    assert abs(lit.sum() - math.pi * r_pix ** 2) < 0.08 * math.pi * r_pix ** 2
+    inner = np.zeros_like(lit); yy, xx = np.mgrid[0:64, 0:64]
+    inner[(xx - 31.5) ** 2 + (yy - 31.5) ** 2 < (r_pix - 1.5) ** 2] = True
+    if sem == 0:
+        np.testing.assert_array_equal(img[inner][:, :3], np.tile(np.float32([5, 4, 3]), (inner.sum(), 1)))
+    else:       # RayTracing.glsl:301: uint(255*c) per sample, / (255*spp)
+        np.testing.assert_allclose(img[inner][:, :3], np.tile([5, 4, 3], (inner.sum(), 1)), rtol=1e-6)
+    ever = np.zeros_like(lit)
+    for smp in range(4):
+        ever |= orc.trace(shapes, np.zeros(0, rta.TRIANGLE_DTYPE), cam, p, smp)[0][:, :, 0] == 0
+    assert np.all(img[~ever][:, :3] == 0)
+    assert np.all(mat[lit][:, 0] == 0) and np.all(hit[:, :, 1] == -2)        # path ends at the light
+    assert st["samples"] == 64 * 64 * 4 and st["terminal"] == st["samples"] and st["segments"] == st["samples"]
+
+
+def test_depth_rules(rta, orc):
+    """max_depth counts ray segments: 1 -> only directly visible emitters (rayTracer.h:113-115, glsl:263)."""
+    cfg = rta.scenes.config1(48, 48, 4, 1)
+    p = orc.params(48, 48, 4, 1)
+    acc, st = orc.render(cfg.shapes, cfg.triangles, cfg.camera, p)
+    assert st["segments"] == st["samples"]
+    ever = np.zeros((48, 48), bool)
+    for smp in range(4):
+        ever |= orc.trace(cfg.shapes, cfg.triangles, cfg.camera, p, smp)[0][:, :, 0] == 3
+    img = acc.view(np.float32)
+    assert ever.any() and np.all(img[~ever][:, :3] == 0) and np.all(img[ever][:, :3] > 0)
+    p8 = orc.params(48, 48, 4, 8)
+    _, st8 = orc.render(cfg.shapes, cfg.triangles, cfg.camera, p8)
+    assert st8["segments"] > st["segments"] and st8["segments"] <= 8 * st8["samples"]
+    assert st8["diffuse"] + st8["terminal"] >= st8["segments"] - st8["samples"]
+
+
+def test_recursive_and_forward_products_agree(rta, orc):
+    """rayTracer.h:121 multiplies on the way out of the recursion; the forward running product differs
+    only by rounding, and the paths (hit ids) are the same."""
+    cfg = rta.scenes.config4(40, 24, 16, 11)
+    pa = orc.params(40, 24, 16, 11, color_order=orc.COLOR_AS_WRITTEN)
+    pf = orc.params(40, 24, 16, 11, color_order=orc.COLOR_FORWARD)
+    a, sa = orc.render(cfg.shapes, cfg.triangles, cfg.camera, pa)
+    f, sf = orc.render(cfg.shapes, cfg.triangles, cfg.camera, pf)
+    assert sa == sf
+    np.testing.assert_allclose(a.view(np.float32), f.view(np.float32), rtol=2e-6, atol=1e-7)
+    ha, ma = orc.trace(cfg.shapes, cfg.triangles, cfg.camera, pa, 5)
+    hf, mf = orc.trace(cfg.shapes, cfg.triangles, cfg.camera, pf, 5)
+    np.testing.assert_array_equal(ha, hf); np.testing.assert_array_equal(ma, mf)
+
+
+def test_direct_sphere_sampler_matches_normalised_gaussians(rta, orc):
+    """utils.h:45 normalises three normal deviates; the oracle samples the same distribution directly.
+    Two renders of the same scene must agree to within Monte-Carlo noise."""
+    cfg = rta.scenes.config1(32, 32, 1024, 6)
+    pd = orc.params(32, 32, 1024, 6, seed=11, unit_sampler=orc.UNIT_DIRECT)
+    pg = orc.params(32, 32, 1024, 6, seed=12, unit_sampler=orc.UNIT_GAUSS)
+    pd2 = orc.params(32, 32, 1024, 6, seed=13, unit_sampler=orc.UNIT_DIRECT)
+    d = orc.render(cfg.shapes, cfg.triangles, cfg.camera, pd)[0].view(np.float32)[..., :3] / 1024
+    g = orc.render(cfg.shapes, cfg.triangles, cfg.camera, pg)[0].view(np.float32)[..., :3] / 1024
+    d2 = orc.render(cfg.shapes, cfg.triangles, cfg.camera, pd2)[0].view(np.float32)[..., :3] / 1024
+    noise = np.abs(d - d2).mean()                    # two seeds of the same sampler
+    assert np.abs(d - g).mean() < 1.5 * noise + 1e-4
+    assert abs(d.mean() - g.mean()) < 0.05 * d.mean()
+
+
+def test_glsl_quantisation_and_resolve(rta, orc):
+    """Light (1.5,1.5,1.5) -> uint(382) per sample (RayTracing.glsl:301), resolve / (255*spp) (PixelConversion.glsl:17)."""
+    shapes = rta.pack([rta.Box((1, 1, -3), (2, 2, 2), rta.Light((1.5, 1.5, 1.5)))], rta.SHAPE_DTYPE)
+    cam = rta.Camera(16, 16).data
+    p = orc.params(16, 16, 7, 10, semantics=1)
+    acc, _ = orc.render(shapes, np.zeros(0, rta.TRIANGLE_DTYPE), cam, p)
+    assert acc[8, 8, 0] == 7 * 382 and acc[8, 8, 3] == 0
+    img = orc.resolve(acc, 7, 1)
+    assert img[16 - 1 - 8, 8, 0] == np.float32(np.float32(7 * 382) / np.float32(255 * 7)) and img[0, 0, 3] == 1.0
+
+
+def test_resolve_flip_gamma_and_running_mean(orc):
+    rng = np.random.RandomState(0)
+    acc = rng.uniform(0, 50, (6, 5, 4)).astype(np.float32)
+    img = orc.resolve(acc.view(np.uint32), 10, 0, gamma_sqrt=True, flip_rows=True)
+    np.testing.assert_array_equal(img[::-1, :, :3], np.sqrt(acc[..., :3] / np.float32(10)))    # rayTracer.h:78,105
+    assert np.all(img[..., 3] == 1)
+    # PixelConversion.glsl:21-23 over three frames == mean of the frames
+    image = np.zeros((6, 5, 4), np.float32)
+    frames = [rng.randint(0, 255 * 100, (6, 5, 4)).astype(np.uint32) for _ in range(3)]
+    for n, f in enumerate(frames, 1):
+        a = f.copy()
+        orc.convert(a, image, 100, 1, n)
+        assert not a.any()                                                                    # :25-27
+    want = sum(f[::-1, :, :3].astype(np.float64) / 25500 for f in frames) / 3
+    np.testing.assert_allclose(image[..., :3], want, rtol=1e-5)
+    np.testing.assert_allclose(image[..., 3], 1.0, rtol=1e-6)
+
+
+def test_row_shards_partition_the_frame(rta, orc):
+    cfg = rta.scenes.config1(40, 50, 4, 4)
+    full, sfull = orc.render(cfg.shapes, cfg.triangles, cfg.camera, orc.params(40, 50, 4, 4))
+    total = np.zeros_like(full); segs = 0
+    for r in range(3):
+        part, st = orc.render(cfg.shapes, cfg.triangles, cfg.camera, orc.params(40, 50, 4, 4, shard=(r, 3, 16)))
+        rows = [y for y in range(50) if (y // 16) % 3 == r]
+        other = [y for y in range(50) if (y // 16) % 3 != r]
+        assert not part[other].any()
+        np.testing.assert_array_equal(part[rows], full[rows])
+        total += part; segs += st["segments"]
+    np.testing.assert_array_equal(total, full)
+    assert segs == sfull["segments"]
+
+
+def test_progressive_chunks_equal_one_shot(rta, orc):
+    """Sums continue across calls in sample order, so 16 = 4+4+8 samples bit for bit."""
+    cfg = rta.scenes.config1(24, 24, 16, 5)
+    one, _ = orc.render(cfg.shapes, cfg.triangles, cfg.camera, orc.params(24, 24, 16, 5))
+    acc = None
+    for first, n in ((0, 4), (4, 4), (8, 8)):
+        acc, _ = orc.render(cfg.shapes, cfg.triangles, cfg.camera, orc.params(24, 24, n, 5, first_sample=first), accum=acc)
+    np.testing.assert_array_equal(acc, one)
