@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s of the path tracer on the 1080p sphere scene.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one full frame of the workload: clear the accumulator, trace `spp` samples per pixel, sum the
+ranks' accumulators (RCCL) when N > 1, resolve on rank 0.  The scene and camera are resident in HBM
+before the timed region.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
+traces its own `spp` samples of every pixel (disjoint sample ranges -> weak scaling: the frame gains
+N x spp samples per pixel), or, with --shard rows, its own interleaved bands of rows.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Algorithmic flop counts (FMA = 2, transcendental = 1), from the reference's own expressions:
+# hitSphere RayTracing.glsl:118-132 ~20, hitBox :138-156 ~58, hitTriangle :179-194 ~32,
+# camera ray :293-298 ~25 + two draws of random() :44-51 (~11 each), a diffuse bounce
+# (advance, normal, randomOnHalfUnitShere :64-80, throughput) ~90, a mirror bounce ~30,
+# a terminal event (light / miss) ~3.
+F_SPHERE, F_BOX, F_TRI = 20, 58, 32
+F_CAMERA, F_DIFFUSE, F_SPECULAR, F_TERMINAL = 25 + 2 * 11, 90, 30, 3
+PEAK_FP32_VECTOR_TFLOPS = 157.3       # 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_flops(st):
+    return (st["samples"] * F_CAMERA + st["sphere_tests"] * F_SPHERE + st["box_tests"] * F_BOX +
+            st["triangle_tests"] * F_TRI + st["diffuse"] * F_DIFFUSE + st["specular"] * F_SPECULAR +
+            st["terminal"] * F_TERMINAL)
+
+
+def cpu_baseline(cfg, target_seconds=12.0):
+    """The CPU oracle (a restatement of the reference's tracer; the reference itself cannot be built
+    here) timed on this host on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    threads = max(1, min(16, os.cpu_count() or 1))
+    p = orc.params(cfg.width, cfg.height, 1, cfg.max_depth, seed=cfg.seed, semantics=cfg.semantics,
+                   sample_mode=cfg.sample_mode, flags=cfg.flags, triangle_albedo=cfg.triangle_albedo, threads=threads)
+    t0 = time.perf_counter()
+    orc.render(cfg.shapes, cfg.triangles, cfg.camera, p)
+    t1 = time.perf_counter() - t0
+    spp = int(max(1, min(cfg.spp, target_seconds / max(t1, 1e-3))))
+    frames = int(max(1, min(64, target_seconds / max(t1 * spp, 1e-3))))
+    p.spp = spp
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        orc.render(cfg.shapes, cfg.triangles, cfg.camera, p)
+    dt = time.perf_counter() - t0
+    n = cfg.width * cfg.height * spp * frames
+    return {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"{frames} frame(s) of {cfg.width}x{cfg.height}, {spp} of {cfg.spp} spp, depth {cfg.max_depth}, "
+                      f"same scene and seed; {dt:.1f} s on {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--shard", default="samples", choices=["samples", "rows"])
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import ray_tracing_amd as rta
+    from ray_tracing_amd import parallel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = rta.scenes.CONFIGS[args.config]()
+    if args.spp:
+        cfg.spp = args.spp
+    shard = parallel.plan(args.shard, rank, world, cfg.spp)
+    rt = rta.scenes.make_renderer(cfg, device=local_rank)
+    rt.setStream(torch.cuda.current_stream().cuda_stream)
+    parallel.apply(rt, shard)
+    accum = torch.zeros(cfg.height, cfg.width, 4, dtype=torch.int32, device="cuda")
+    out = torch.empty(cfg.height, cfg.width, 4, dtype=torch.float32, device="cuda")
+    rt.bindAccum(accum.data_ptr(), cfg.width, cfg.height)
+
+    def step(ev=None):
+        rt.resetAccum()                       # hipMemsetAsync of the bound accumulator on the stream
+        if ev:
+            ev[0].record()
+        rt.render(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, first_sample=shard.first_sample)
+        if ev:
+            ev[1].record()
+        parallel.reduce_framebuffer(accum, cfg.semantics)
+        if rank == 0:
+            rt.setAccumSamples(parallel.total_samples(shard))
+            rt.resolveDevice(out.data_ptr(), gamma_sqrt=(cfg.semantics == rta.SEM_CPU), flip_rows=True)
+
+    # Work counters of one launch (same inputs every step -> same counts); not timed.
+    rt.resetAccum()
+    stats = rt.render(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, first_sample=shard.first_sample, stats=True)
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    samples_per_step_rank = stats["samples"]
+    samples_per_step = samples_per_step_rank
+    if world > 1:
+        s = torch.tensor([samples_per_step_rank], dtype=torch.int64, device="cuda")
+        dist.all_reduce(s)
+        samples_per_step = int(s.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = samples_per_step / (elapsed / args.steps) / 1e6
+        flops = algorithmic_flops(stats)
+        achieved = flops / (kernel_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = f"{args.config}_{cfg.width}x{cfg.height}_{shard.spp}spp"
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        info = rta.device_info(local_rank)
+        result = {
+            "metric": "Msamples/sec at 1080p", "value": round(value, 2), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak" if args.shard == "samples" else "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg.name}: {cfg.width}x{cfg.height}, {shard.spp} spp per GPU, depth {cfg.max_depth}, "
+                                   f"{len(cfg.shapes)} shapes + {len(cfg.triangles)} triangles, "
+                                   f"{'cpu_version' if cfg.semantics == rta.SEM_CPU else 'RayTracing.glsl'} semantics, seed {cfg.seed}",
+                       "shard": args.shard, "spp_total": parallel.total_samples(shard), "device": info["name"]},
+            "mrays_per_s": round(stats["segments"] * world / (elapsed / args.steps) / 1e6, 2),
+            "segments_per_sample": round(stats["segments"] / max(1, stats["samples"]), 4),
+            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4), "traffic": traffic,
+                         "kernel": "trace_kernel", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_flops_per_launch": flops,
+                         "algorithmic_hbm_bytes_per_launch": cfg.width * cfg.height * 32,
+                         "note": "fp32 vector (VALU) bound: no dense contraction, no MFMA; HBM traffic is the framebuffer only"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(result), flush=True)
+
+    rt.bindAccum(None, 0, 0)
+    rt.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -200,6 +200,11 @@ int rt_render_stats(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp,
 /* Number of samples per pixel added to the accumulator since the last reset. */
 int rt_accum_samples(const rt_ctx* ctx, uint32_t* out);
 
+/* Declare that the accumulator now holds `samples` samples per pixel: for a
+ * caller that has summed other GPUs' accumulators into this one.  No
+ * counterpart in the reference. */
+int rt_set_accum_samples(rt_ctx* ctx, uint32_t samples);
+
 /* main.cpp:179,194 (number_of_samples = 1): drop everything accumulated. */
 int rt_reset_accum(rt_ctx* ctx);
 

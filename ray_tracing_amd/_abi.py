@@ -59,6 +59,7 @@ SIGNATURES = {
     "rt_render": (_int, [_vp, _u32, _u32, _u32, _u32, _u64, _u32, _u32]),
     "rt_render_stats": (_int, [_vp, _u32, _u32, _u32, _u32, _u64, _u32, _u32, C.POINTER(Stats)]),
     "rt_accum_samples": (_int, [_vp, C.POINTER(_u32)]),
+    "rt_set_accum_samples": (_int, [_vp, _u32]),
     "rt_reset_accum": (_int, [_vp]),
     "rt_resolve": (_int, [_vp, _vp, _int, _int]),
     "rt_resolve_device": (_int, [_vp, _vp, _int, _int]),
@@ -86,6 +87,13 @@ SIGNATURES = {
 
 
 def _load():
+    # librt_mi355x.so names its HIP runtime "libamdhip64.so"; PyTorch bundles one under that name.
+    # Importing torch first makes both use the SAME runtime, so torch streams, events and device
+    # tensors can be handed to the library.  Without torch the ROCm install's runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -367,6 +367,13 @@ int rt_accum_samples(const rt_ctx* ctx, uint32_t* out)
     return RT_OK;
 }
 
+int rt_set_accum_samples(rt_ctx* ctx, uint32_t samples)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    ctx->accum_samples = samples;
+    return RT_OK;
+}
+
 int rt_reset_accum(rt_ctx* ctx)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;
@@ -414,7 +421,7 @@ int rt_convert(rt_ctx* ctx, uint32_t n_samples)
     if (!accum_ptr(ctx) || ctx->accum_samples == 0) return fail(ctx, RT_ERR_STATE, "convert: nothing has been rendered");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->d_image || ctx->image_w != ctx->width || ctx->image_h != ctx->height) {
-        RT_REQUIRE(ctx, n_samples == 1 || !ctx->d_image ? true : false, "rt_convert: image size changed; restart with n_samples = 1");
+        RT_REQUIRE(ctx, n_samples == 1 || !ctx->d_image, "rt_convert: image size changed; restart with n_samples = 1");
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_image) { RT_HIP(ctx, hipFree(ctx->d_image)); ctx->d_image = nullptr; }
         const size_t bytes = (size_t)ctx->width * ctx->height * 16u;

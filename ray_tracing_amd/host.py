@@ -274,6 +274,9 @@ class RayTracingComputeShader:
         self._check(lib.rt_reset_accum(self._ctx))
         self.frame = 0
 
+    def setAccumSamples(self, n):
+        self._check(lib.rt_set_accum_samples(self._ctx, n))
+
     def accumSamples(self):
         n = C.c_uint32()
         self._check(lib.rt_accum_samples(self._ctx, C.byref(n)))

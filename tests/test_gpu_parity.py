@@ -156,7 +156,7 @@ def test_row_shards_reassemble_bit_exact(rta, orc):
         total += part.view(torch.float32)
     rt.bindAccum(None, 0, 0)
     rt.close()
-    ref = (total[..., :3] / 6).cpu().numpy()[::-1]
+    ref = (total[..., :3].cpu().numpy() / np.float32(6))[::-1]      # IEEE division on the host
     np.testing.assert_array_equal(ref.view(np.uint32), whole[..., :3].copy().view(np.uint32))
 
 
