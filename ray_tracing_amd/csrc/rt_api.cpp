@@ -166,6 +166,10 @@ int rt_upload_shapes(rt_ctx* ctx, const rt_shape* shapes, uint32_t n)
         d.mat_type = s.material.type;
         d.fuzz = s.material.data[1];
         d.r = s.material.color[0]; d.g = s.material.color[1]; d.b = s.material.color[2];
+        if (ctx->cfg.semantics == RT_SEM_CPU && s.material.type == RT_MAT_LAMBERTIAN) {
+            // Lambertian::scatter attenuates by 0.6 * albedo (scene.h:56): formed once here.
+            d.r = d.r * 0.6f; d.g = d.g * 0.6f; d.b = d.b * 0.6f;
+        }
         d.ior = s.material.data[0];
     }
     // The kernels may still be reading the old copy.
@@ -282,7 +286,8 @@ static int fill_params(rt_ctx* ctx, rtd::TraceParams& P, uint32_t width, uint32_
     RT_REQUIRE(ctx, ctx->have_camera, "render: rt_set_camera has not been called");
     memset(&P, 0, sizeof P);
     memcpy(P.cam, ctx->cam, sizeof P.cam);
-    memcpy(P.tri_albedo, ctx->cfg.triangle_albedo, sizeof P.tri_albedo);
+    for (int k = 0; k < 3; ++k)     // triangles are Lambertian (glsl:275); CPU rules attenuate by 0.6 * albedo (scene.h:56)
+        P.tri_albedo[k] = ctx->cfg.semantics == RT_SEM_CPU ? ctx->cfg.triangle_albedo[k] * 0.6f : ctx->cfg.triangle_albedo[k];
     P.width = width; P.height = height;
     P.n_shapes = ctx->n_shapes; P.n_tris = ctx->n_tris;
     P.spp = spp; P.first_sample = first_sample; P.max_depth = max_depth;

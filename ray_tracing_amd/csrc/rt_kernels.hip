@@ -41,7 +41,38 @@ RT_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 RT_DEV float dot(V3 a, V3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 // o + t*d
 RT_DEV V3 madd(float t, V3 d, V3 o) { return v3(fma_(t, d.x, o.x), fma_(t, d.y, o.y), fma_(t, d.z, o.z)); }
-RT_DEV V3 normalize(V3 v) { float inv = 1.0f / __builtin_sqrtf(dot(v, v)); return v * inv; }
+// 1/sqrt(q): bit-trick first guess + three Newton steps, every step an IEEE
+// operation (relative error <= 1.3e-7).  A third of the issue slots of a
+// correctly rounded sqrt followed by a correctly rounded divide, and — unlike
+// v_rsq_f32 — reproducible bit for bit on a CPU.
+RT_DEV float rsqrt_nr(float q)
+{
+    float y = __uint_as_float(0x5f3759dfu - (__float_as_uint(q) >> 1));
+    const float h = 0.5f * q;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float t = h * y;
+        float e = fma_(-t, y, 1.5f);
+        y = y * e;
+    }
+    return y;
+}
+RT_DEV V3 normalize(V3 v) { return v * rsqrt_nr(dot(v, v)); }
+// Correctly rounded sqrt: v_sqrt_f32 (within 1 ulp) plus a residual test against each
+// neighbour — the sequence hipcc emits for sqrtf, without its range scaling.  Arguments in
+// (0, 2^-96), where the residuals would go subnormal, take the compiler's general sequence
+// when GUARD is set; callers whose argument cannot be that small pass GUARD = false.
+template <bool GUARD>
+RT_DEV float sqrt_rn(float x)
+{
+    if (GUARD && __builtin_expect(__any((__float_as_uint(x) - 1u) < 0x0f7fffffu), 0)) return __builtin_sqrtf(x);
+    float s = __builtin_amdgcn_sqrtf(x);
+    float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    float rm = fma_(-sm, s, x), rp = fma_(-sp, s, x);
+    s = (rm <= 0.0f) ? sm : s;
+    s = (rp > 0.0f) ? sp : s;
+    return s;
+}
 RT_DEV V3 cross(V3 a, V3 b)
 {
     return v3(fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x)));
@@ -105,7 +136,7 @@ RT_DEV void sincos2pi(float u, float& c_out, float& s_out)
 RT_DEV V3 unit_vector(float u1, float u2)
 {
     float z = fma_(-2.0f, u1, 1.0f);
-    float r = __builtin_sqrtf(fma_(-z, z, 1.0f));
+    float r = sqrt_rn<false>(fma_(-z, z, 1.0f));     // 1 - z*z is 0 or >= 2^-23
     float c, s;
     sincos2pi(u2, c, s);
     return v3(r * c, r * s, z);
@@ -117,13 +148,13 @@ RT_DEV V3 hemisphere_glsl(V3 n, float u1, float u2)
     float c, s;
     sincos2pi(u1, c, s);
     float r = u2;
-    float dist = __builtin_sqrtf(fma_(-r, r, 1.0f));
+    float dist = sqrt_rn<false>(fma_(-r, r, 1.0f));  // 1 - r*r >= 2^-24
     float x = c * dist, y = s * dist;
-    float q = fma_(n.x, n.x, n.y * n.y);          // |(-n.y, n.x)|^2
-    float len_xy = __builtin_sqrtf(q);
+    float q = fma_(n.x, n.x, n.y * n.y);          // |(-n.y, n.x, 0)|^2
+    float len_xy = sqrt_rn<true>(q);
     V3 b1;
     if (len_xy < 0.01f) b1 = normalize(v3(0.0f, -n.z, n.y));
-    else { float inv = 1.0f / len_xy; b1 = v3(-n.y * inv, n.x * inv, 0.0f * inv); }
+    else { float inv = rsqrt_nr(q); b1 = v3(-n.y * inv, n.x * inv, 0.0f * inv); }
     V3 b2 = cross(n, b1);
     return v3(fma_(n.x, r, fma_(b2.x, y, b1.x * x)),
               fma_(n.y, r, fma_(b2.y, y, b1.y * x)),
@@ -139,8 +170,7 @@ RT_DEV float hit_sphere(float cx, float cy, float cz, float r2, V3 o, V3 d)
     float b = dot(oc, d);
     float c = dot(oc, oc) - r2;
     float disc = fma_(b, b, -c);
-    float t = -b - __builtin_sqrtf(disc);
-    return (disc < 0.0f) ? __builtin_inff() : t;
+    return -b - sqrt_rn<true>(disc);       // disc < 0 gives NaN, which every later comparison rejects
 }
 
 // hitBox, RayTracing.glsl:138-156.
@@ -192,10 +222,9 @@ RT_DEV float hit_triangle(const DevTriangle& tr, V3 o, V3 d)
 // arguments of rayTracer.h:117 (t_min is the double 0.001 compared with a
 // widened float, true exactly when t >= 0.001f).  Shader: RayTracing.glsl:212.
 template <int SEM>
-RT_DEV bool in_window(float t)
+RT_DEV bool in_window_near(float t)
 {
-    if (SEM == 0) return t >= 0.001f && t < 3.402823466e+38f;
-    return t < 1000.0f && t > 0.0001f;
+    return (SEM == 0) ? (t >= 0.001f) : (t > 0.0001f);
 }
 
 // uvec4(255 * color), RayTracing.glsl:301; negative and NaN give 0, large
@@ -206,47 +235,17 @@ RT_DEV uint32_t quantise(float c)
     return (v > 0.0f) ? ((v >= 4294967296.0f) ? 0xffffffffu : (uint32_t)v) : 0u;
 }
 
-struct PixelCtx {
-    V3 pc;            // world position of the pixel's corner
-    uint32_t h1;      // hash32(seed_key ^ pixel index)
-};
-
-// Camera ray of one sample: RayTracing.glsl:293-298 (jitter) or renderPixel<N>,
-// src/cpu_version/rayTracer.h:92-101 (grid).
-RT_DEV void camera_ray(const TraceParams& P, const PixelCtx& px, uint32_t sample, uint32_t& key, V3& o, V3& d)
-{
-    const float step = P.cam[19];
-    const V3 pos = v3(P.cam[0], P.cam[1], P.cam[2]);
-    const V3 up = v3(P.cam[12], P.cam[13], P.cam[14]);
-    const V3 right = v3(P.cam[16], P.cam[17], P.cam[18]);
-    key = hash32(px.h1 ^ sample);
-    if (P.sample_mode == 0) {
-        float s1 = step * draw(key, 0u), s2 = step * draw(key, 1u);
-        o = madd(-s2, up, madd(s1, right, px.pc));
-    } else {
-        uint32_t N = P.grid_n;
-        uint32_t i = (sample / N) % N, j = sample % N;
-        float step_size = step / (float)(N + 1u);
-        V3 ups = up * step_size, rs = right * step_size;
-        o = px.pc - ups * (float)i;
-        if (P.sample_mode == 2) {
-            for (uint32_t jj = 0; jj <= j; ++jj) {
-                V3 inc = rs * (float)jj;
-                o = v3(o.x + inc.x, o.y + inc.y, o.z + inc.z);
-            }
-        } else {
-            V3 inc = rs * (float)j;
-            o = v3(o.x + inc.x, o.y + inc.y, o.z + inc.z);
-        }
-    }
-    d = normalize(o - pos);
-}
-
 // -------------------------------------------------------------- the tracer
 // SEM 0: rules of src/cpu_version (rayTracer.h:110-132, scene.h:39-109).
 // SEM 1: rules of RayTracing.glsl:233-288.
 // STATS: count work.  TRACE: follow one sample, record hit and material ids,
 // leave the accumulator alone.
+//
+// One loop iteration = one ray segment of every live lane: closest hit, then
+// the surface event.  Lanes whose path ended start their next sample in the
+// same iteration, and the two expensive steps every continuing lane needs —
+// two random draws and the normalisation of the new direction — are issued
+// once for the whole wave, whether a lane is bouncing or starting a sample.
 template <int SEM, bool STATS, bool TRACE>
 __global__ __launch_bounds__(BLOCK)
 void trace_kernel(const TraceParams P,
@@ -266,16 +265,13 @@ void trace_kernel(const TraceParams P,
     const bool valid = gx < P.width && row < P.owned_rows && gy < P.height;
 
     const uint32_t pixel = gy * P.width + gx;
-    PixelCtx px;
-    {
-        const float step = P.cam[19];
-        const V3 ul = v3(P.cam[8], P.cam[9], P.cam[10]);
-        const V3 up = v3(P.cam[12], P.cam[13], P.cam[14]);
-        const V3 right = v3(P.cam[16], P.cam[17], P.cam[18]);
-        float sx = step * (float)gx, sy = step * (float)gy;
-        px.pc = madd(-sy, up, madd(sx, right, ul));
-        px.h1 = hash32(P.seed_key ^ pixel);
-    }
+    const float step = P.cam[19];
+    const V3 cam_pos = v3(P.cam[0], P.cam[1], P.cam[2]);
+    const V3 cam_up = v3(P.cam[12], P.cam[13], P.cam[14]);
+    const V3 cam_right = v3(P.cam[16], P.cam[17], P.cam[18]);
+    // rayTracer.h:77 / glsl:293: upperLeft + step*gx*right - step*gy*up
+    const V3 pc = madd(-(step * (float)gy), cam_up, madd(step * (float)gx, cam_right, v3(P.cam[8], P.cam[9], P.cam[10])));
+    const uint32_t h1 = hash32(P.seed_key ^ pixel);
 
     // Running sums of this pixel: float for SEM 0, uint for SEM 1.
     uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
@@ -291,16 +287,49 @@ void trace_kernel(const TraceParams P,
     const uint32_t sample_end = TRACE ? P.trace_sample + 1u : P.first_sample + P.spp;
     bool alive = valid && sample < sample_end;
 
+    // Origin and un-normalised direction of the camera ray of `sample`:
+    // RayTracing.glsl:296-297 (jitter, from two draws) or renderPixel<N>,
+    // src/cpu_version/rayTracer.h:92-101 (grid).
+    auto camera_origin = [&](uint32_t smp, float u1, float u2) -> V3 {
+        if (P.sample_mode == 0u) {
+            float s1 = step * u1, s2 = step * u2;
+            return madd(-s2, cam_up, madd(s1, cam_right, pc));
+        }
+        const uint32_t N = P.grid_n;
+        const uint32_t i = (smp / N) % N, j = smp % N;
+        const float step_size = step / (float)(N + 1u);
+        const V3 ups = cam_up * step_size, rs = cam_right * step_size;
+        V3 org = pc - ups * (float)i;
+        if (P.sample_mode == 2u) {
+            for (uint32_t jj = 0; jj <= j; ++jj) {
+                V3 inc = rs * (float)jj;
+                org = v3(org.x + inc.x, org.y + inc.y, org.z + inc.z);
+            }
+        } else {
+            V3 inc = rs * (float)j;
+            org = v3(org.x + inc.x, org.y + inc.y, org.z + inc.z);
+        }
+        return org;
+    };
+
     uint32_t key = 0, bounce = 0;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1), thr = v3(1, 1, 1);
-    if (alive) { camera_ray(P, px, sample, key, o, d); if (STATS) ++n_samples; }
+    if (alive) {
+        key = hash32(h1 ^ sample);
+        o = camera_origin(sample, draw(key, 0u), draw(key, 1u));
+        d = normalize(o - cam_pos);
+        if (STATS) ++n_samples;
+    }
 
     const uint32_t n_shapes = P.n_shapes, n_tris = P.n_tris;
+    const float t_far = (SEM == 0) ? 3.402823466e+38f : 1000.0f;   // scene.h:237 / glsl:212
 
     while (alive) {
         // ---- closest hit: Scene::hit (scene.h:232-255) /
-        //      getClosestShapeIndex + getClosestTriangleIndex (glsl:206-231)
-        float best = __builtin_inff();
+        //      getClosestShapeIndex + getClosestTriangleIndex (glsl:206-231).
+        //      `best` starts at the far end of the window, so `t < best`
+        //      also is the window's upper test; a NaN t fails both tests.
+        float best = t_far;
         int index = -1;
         for (uint32_t i = 0; i < n_shapes; ++i) {
             const DevShape& s = shapes[i];
@@ -308,109 +337,60 @@ void trace_kernel(const TraceParams P,
             if (s.type == 0u) t = hit_sphere(s.cx, s.cy, s.cz, s.p0, o, d);
             else if (s.type == 1u) t = hit_box(s.cx, s.cy, s.cz, s.p1, o, d);
             else t = -1.0f;
-            if (in_window<SEM>(t) && t < best) { best = t; index = (int)i; }
+            if (in_window_near<SEM>(t) && t < best) { best = t; index = (int)i; }
         }
-        float best_tri = __builtin_inff();
+        float best_tri = t_far;
         int index_tri = -1;
         for (uint32_t i = 0; i < n_tris; ++i) {
             float t = hit_triangle(tris[i], o, d);
-            if (in_window<SEM>(t) && t < best_tri) { best_tri = t; index_tri = (int)i; }
+            if (in_window_near<SEM>(t) && t < best_tri) { best_tri = t; index_tri = (int)i; }
         }
         if (STATS) ++n_segments;
 
-        bool ended = false;
-        V3 color = v3(0, 0, 0);           // what the path returns if it ends here
+        // ---- the surface
+        uint32_t type = 0xffffffffu;           // nothing hit
         int hit_id = -1;
-        uint32_t mat_id = 0xffffffffu;
-
-        if (index < 0 && index_tri < 0) {
-            ended = true;                  // rayTracer.h:131 / glsl:267-269: black
-        } else {
-            V3 n, albedo;
-            uint32_t type;
-            float fuzz = 0.0f;
-            const bool is_tri = best_tri < best;          // glsl:271
-            const float t = is_tri ? best_tri : best;
-            const V3 p = madd(t, d, o);                   // Ray::at / glsl:239
-            if (is_tri) {
-                const DevTriangle& tr = tris[index_tri];
-                V3 a = v3(tr.ax, tr.ay, tr.az);
-                n = a * sign_(-dot(d, a));                // glsl:165-167,272
-                albedo = v3(P.tri_albedo[0], P.tri_albedo[1], P.tri_albedo[2]);
-                type = 1u;
-                hit_id = (int)n_shapes + index_tri;
-            } else {
-                const DevShape s = shapes[index];
-                if (s.type == 0u) n = normalize(v3(p.x - s.cx, p.y - s.cy, p.z - s.cz));  // scene.h:130-132
-                else if (s.type == 1u) n = box_normal(s.cx, s.cy, s.cz, s.p0, p);
-                else n = v3(1.0f, 1.0f, 1.0f);            // glsl:203
-                albedo = v3(s.r, s.g, s.b);
-                type = s.mat_type;
-                fuzz = s.fuzz;
-                hit_id = index;
-            }
-            mat_id = type;
-            const uint32_t di = bounce_draw(bounce);
-
-            if (type == 1u) {
-                float u1 = draw(key, di), u2 = draw(key, di + 1u);
-                if (SEM == 0) {
-                    // Lambertian::scatter, scene.h:51-58; utils.h:48-50
-                    V3 u = unit_vector(u1, u2);
-                    d = normalize(madd(1.0001f, n, u));
-                    thr = thr * (albedo * 0.6f);
-                } else {
-                    // glsl:238-242 and :273-275
-                    d = hemisphere_glsl(n, u1, u2);
-                    thr = thr * albedo;
-                }
-                o = p;
-                if (STATS) ++n_diffuse;
-            } else if (type == 2u) {
-                if (STATS) ++n_specular;
-                if (SEM == 0) {
-                    // Metal::scatter, scene.h:73-81; reflect, utils.h:62-64
-                    float k = 2.0f * dot(n, d);
-                    V3 dir = madd(-k, n, d);
-                    if (fuzz != 0.0f) {
-                        float u1 = draw(key, di), u2 = draw(key, di + 1u);
-                        dir = madd(fuzz, unit_vector(u1, u2), dir);
-                    }
-                    if (!(dot(dir, n) > 0.0f)) {
-                        ended = true;                     // absorbed: emit() = 0
-                    } else {
-                        d = (P.flags & 1u) ? dir : normalize(dir);
-                        o = p;
-                        thr = thr * albedo;
-                    }
-                } else {
-                    // glsl:243-247; reflect :82-84
-                    float k = 2.0f * dot(d, n);
-                    d = normalize(madd(-k, n, d));
-                    o = p;
-                    thr = thr * albedo;
-                }
-            } else if (type == 0u) {
-                color = thr * albedo;                     // LightSource::emit / glsl:278-280
-                ended = true;
-            } else if (type == 100u) {
-                color = (SEM == 0) ? thr * n : n;         // glsl:248-252
-                ended = true;
-            } else {
-                color = (SEM == 0) ? v3(0, 0, 0) : thr;   // glsl:253,282-284
-                ended = true;
-            }
+        V3 n = v3(0, 0, 0), att = v3(0, 0, 0);
+        float fuzz = 0.0f;
+        const bool is_tri = index_tri >= 0 && best_tri < best;        // glsl:271
+        const V3 p = madd(is_tri ? best_tri : best, d, o);            // Ray::at / glsl:239
+        if (is_tri) {
+            const DevTriangle& tr = tris[index_tri];
+            V3 a = v3(tr.ax, tr.ay, tr.az);
+            n = a * sign_(-dot(d, a));                                // glsl:165-167,272
+            att = v3(P.tri_albedo[0], P.tri_albedo[1], P.tri_albedo[2]);
+            type = 1u;
+            hit_id = (int)n_shapes + index_tri;
+        } else if (index >= 0) {
+            const DevShape s = shapes[index];
+            if (s.type == 0u) n = normalize(v3(p.x - s.cx, p.y - s.cy, p.z - s.cz));     // scene.h:130-132
+            else if (s.type == 1u) n = box_normal(s.cx, s.cy, s.cz, s.p0, p);
+            else n = v3(1.0f, 1.0f, 1.0f);                            // glsl:203
+            att = v3(s.r, s.g, s.b);
+            type = s.mat_type;
+            fuzz = s.fuzz;
+            hit_id = index;
         }
-
         if (TRACE) {
             size_t at = (size_t)pixel * P.max_depth + bounce;
             trace_hit[at] = hit_id;
-            trace_mat[at] = mat_id;
+            trace_mat[at] = type;
         }
 
-        ++bounce;
-        if (!ended && bounce >= P.max_depth) ended = true;   // rayTracer.h:113-115 / glsl:263,287
+        const bool last = bounce + 1u >= P.max_depth;                 // rayTracer.h:113-115 / glsl:263,287
+        bool ended = true;
+        bool raw_dir = false;                                         // new direction is used as it is
+        V3 color = v3(0, 0, 0);                                       // what the path returns if it ends here
+        V3 v = v3(0, 0, 1);                                           // new direction before normalisation
+        const bool diffuse = type == 1u, metal = type == 2u;
+        if (STATS) { n_diffuse += diffuse ? 1u : 0u; n_specular += metal ? 1u : 0u; }
+        if (type == 0u) color = thr * att;                            // LightSource::emit / glsl:278-280
+        else if (type == 100u) color = (SEM == 0) ? thr * n : n;      // glsl:248-252
+        else if (!diffuse && !metal && type != 0xffffffffu) color = (SEM == 0) ? v3(0, 0, 0) : thr;   // glsl:253,282-284
+        else if ((diffuse || metal) && !last) ended = false;
 
+        // Two draws per lane: the bounce's pair, or — for a lane that starts a
+        // sample — the jitter pair of the new sample.
         if (ended) {
             if (STATS) ++n_terminal;
             if (SEM == 0) {
@@ -423,15 +403,59 @@ void trace_kernel(const TraceParams P,
                 acc2 += quantise(color.z);
             }
             ++sample;
-            if (sample < sample_end) {
-                camera_ray(P, px, sample, key, o, d);
-                thr = v3(1, 1, 1);
-                bounce = 0;
-                if (STATS) ++n_samples;
+            alive = sample < sample_end;
+            key = hash32(h1 ^ sample);
+            if (STATS && alive) ++n_samples;
+        }
+        const uint32_t di = ended ? 0u : bounce_draw(bounce);
+        const float u1 = draw(key, di), u2 = draw(key, di + 1u);
+
+        if (ended) {
+            o = camera_origin(sample, u1, u2);
+            v = o - cam_pos;                                          // rayTracer.h:100 / glsl:297
+            thr = v3(1, 1, 1);
+            bounce = 0;
+        } else {
+            ++bounce;
+            o = p;
+            thr = thr * att;                                          // scene.h:56 (0.6*albedo, formed at upload), :79; glsl:241,246,275
+            if (diffuse) {
+                if (SEM == 0) {
+                    v = madd(1.0001f, n, unit_vector(u1, u2));        // Lambertian::scatter, scene.h:51-58; utils.h:48-50
+                } else {
+                    v = hemisphere_glsl(n, u1, u2);                   // glsl:240,274
+                    raw_dir = true;
+                }
+            } else if (SEM == 0) {
+                // Metal::scatter, scene.h:73-81; reflect, utils.h:62-64
+                v = madd(-(2.0f * dot(n, d)), n, d);
+                if (fuzz != 0.0f) v = madd(fuzz, unit_vector(u1, u2), v);
+                raw_dir = (P.flags & 1u) != 0u;
+                if (!(dot(v, n) > 0.0f)) {
+                    // absorbed: emit() = 0 (scene.h:80,83-85).  The path ends here after all;
+                    // this rare case starts the next sample with draws of its own.
+                    if (STATS) ++n_terminal;
+                    if (SEM == 0) {
+                        acc0 = __float_as_uint(__uint_as_float(acc0) + 0.0f);
+                        acc1 = __float_as_uint(__uint_as_float(acc1) + 0.0f);
+                        acc2 = __float_as_uint(__uint_as_float(acc2) + 0.0f);
+                    }
+                    ++sample;
+                    alive = sample < sample_end;
+                    key = hash32(h1 ^ sample);
+                    if (STATS && alive) ++n_samples;
+                    o = camera_origin(sample, draw(key, 0u), draw(key, 1u));
+                    v = o - cam_pos;
+                    thr = v3(1, 1, 1);
+                    bounce = 0;
+                    raw_dir = false;
+                }
             } else {
-                alive = false;
+                v = madd(-(2.0f * dot(d, n)), n, d);                  // glsl:243-247; reflect :82-84
             }
         }
+        const V3 nd = normalize(v);
+        d = raw_dir ? v : nd;
     }
 
     if (!TRACE && valid) {
