@@ -196,7 +196,8 @@ float orc_hit_sphere(const float cc[3], float radius, const float oo[3], const f
     v3 oc = vsub(V(oo[0], oo[1], oo[2]), V(cc[0], cc[1], cc[2]));   /* scene.h:116 */
     v3 d = V(dd[0], dd[1], dd[2]);
     float b = dot(oc, d);                                            /* :117 */
-    float c = dot(oc, oc) - radius * radius;                         /* :118 */
+    float r2 = radius * radius;
+    float c = fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, fmaf(oc.x, oc.x, -r2)));   /* :118 */
     float disc = fmaf(b, b, -c);                                     /* :119 */
     if (disc < 0.0f) return INFINITY;                                /* :120 */
     return -b - sqrtf(disc);                                         /* :123 */

@@ -168,8 +168,12 @@ RT_DEV float hit_sphere(float cx, float cy, float cz, float r2, V3 o, V3 d)
 {
     V3 oc = v3(o.x - cx, o.y - cy, o.z - cz);
     float b = dot(oc, d);
-    float c = dot(oc, oc) - r2;
+    float c = fma_(oc.z, oc.z, fma_(oc.y, oc.y, fma_(oc.x, oc.x, -r2)));   // oc.oc - r*r
     float disc = fma_(b, b, -c);
+    // The root -b - sqrt(disc) can only lie in the window (t > 0) when b < 0 and disc >= 0.
+    // When that holds for no lane of the wave the square root is skipped; the NaN returned
+    // instead fails every comparison, exactly as the skipped value would have.
+    if (!__any(b < 0.0f && disc >= 0.0f)) return __builtin_nanf("");
     return -b - sqrt_rn<true>(disc);       // disc < 0 gives NaN, which every later comparison rejects
 }
 
