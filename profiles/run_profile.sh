@@ -13,4 +13,4 @@ timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST
 timeout -s KILL 120 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS --output-format csv -d "$OUT/pmc2" -- $BENCH > "$OUT/pmc2.log" 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc3" -- $BENCH > "$OUT/pmc3.log" 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE GRBM_COUNT --output-format csv -d "$OUT/pmc4" -- $BENCH > "$OUT/pmc4.log" 2>&1
-find "$OUT" -name "*.csv" | head -50
+ls "$OUT"
