@@ -48,8 +48,8 @@ struct TraceParams {
 // Slots of the statistics block (uint64 each).
 enum { ST_SAMPLES = 0, ST_SEGMENTS, ST_DIFFUSE, ST_SPECULAR, ST_TERMINAL, ST_COUNT };
 
-constexpr int TILE_W = 16;     // pixels per workgroup in x (two 8-wide wave tiles)
-constexpr int TILE_H = 16;     // and in y
-constexpr int BLOCK = 256;
+constexpr int TILE_W = 8;      // pixels per workgroup in x (two 8-wide wave tiles)
+constexpr int TILE_H = 8;      // and in y
+constexpr int BLOCK = 64;
 
 }  // namespace rtd

@@ -263,7 +263,7 @@ void trace_kernel(const TraceParams P,
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     const uint32_t gx = blockIdx.x * TILE_W + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t row = blockIdx.y * TILE_H + (wave >> 1) * 8u + (lane >> 3);   // ordinal among owned rows
+    const uint32_t row = (gridDim.y - 1u - blockIdx.y) * TILE_H + (wave >> 1) * 8u + (lane >> 3);   // ordinal among owned rows
     const uint32_t band = row / P.band_rows;
     const uint32_t gy = (band * P.shard_count + P.shard_index) * P.band_rows + (row - band * P.band_rows);
     const bool valid = gx < P.width && row < P.owned_rows && gy < P.height;

@@ -219,3 +219,33 @@ def test_argument_errors(rta):
     with pytest.raises(rta.RtError):
         rt2.render(8, 8, 1, 2, 1)          # camera never set
     rt2.close()
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = map(int, f.readline().split())
+        assert float(f.readline()) < 0            # little-endian
+        data = np.frombuffer(f.read(), dtype="<f4").reshape(h, w, 3)
+    return data[::-1]                             # PFM stores rows bottom to top
+
+
+def test_headless_cpp_driver_matches_python_host(rta, tmp_path):
+    """examples/headless_main (rt_host.hpp, the frame loop of main.cpp:135-151) == the same frames through host.py."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "headless_main")
+    assert os.path.exists(exe), "examples/headless_main is not built (run __graft_entry__.build())"
+    out = str(tmp_path / "frame.pfm")
+    mesh = os.path.join(rta.scenes.MESH_DIR, "Bunny-LowPoly.off")
+    subprocess.run([exe, "--mesh", mesh, "--frames", "2", "--width", "96", "--height", "54", "--out", out],
+                   check=True, timeout=120)
+    got = read_pfm(out)
+    cfg = rta.scenes.config3(width=96, height=54, spp=100, max_depth=10)
+    rt = rta.scenes.make_renderer(cfg)
+    for n in (1, 2):
+        rt.updateCameraBuffer(); rt.compute(96, 54, 1); rt.convert(n)
+    want = rt.readImage()[..., :3]
+    rt.close()
+    np.testing.assert_array_equal(got.view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
