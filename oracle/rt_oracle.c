@@ -60,6 +60,24 @@ static inline float rsqrt_nr(float q)
     return y;
 }
 static inline v3 normalize(v3 v) { return vscale(v, rsqrt_nr(dot(v, v))); }
+/* 1/x by a fixed recipe: first guess by subtracting the bit pattern from a
+ * constant, then three Newton steps y <- y * (2 - x y), each an IEEE
+ * operation; relative error <= 2e-7 for normal x of either sign, x = 0 gives
+ * +-inf.  a / b in the routines taken from the shader (hitTriangle, hitBox,
+ * boxNormalAt) is a * rcp_nr(b): GLSL specifies its own division only to
+ * 2.5 ulp, and a correctly rounded divide costs the GPU five times as much. */
+static inline float rcp_nr(float x)
+{
+    uint32_t bits; memcpy(&bits, &x, 4);
+    bits = 0x7ef311c7u - bits;
+    float y; memcpy(&y, &bits, 4);
+    for (int k = 0; k < 3; ++k) {
+        float e = fmaf(-x, y, 2.0f);
+        y = y * e;
+    }
+    return y;
+}
+static inline float div_nr(float a, float b) { return a * rcp_nr(b); }
 static inline v3 cross(v3 a, v3 b)
 {
     return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
@@ -108,14 +126,16 @@ float orc_draw(uint32_t key, uint32_t index)
 #define DRAW_BOUNCE(b) (2u + 4u * (uint32_t)(b))
 
 /* cos(2 pi u), sin(2 pi u) for u in [0,1) from fmaf/mul only, so that it is
- * the same function on every machine.  Stands in for the cos/sin of
- * RayTracing.glsl:69-70 and for the angular part of utils.h:45. */
+ * the same function on every machine, and without a quadrant case split: the
+ * half angle h = pi*u - pi/2 lies in [-pi/2, pi/2), where one odd and one even
+ * Taylor polynomial give sin h and cos h; with theta = 2h = 2 pi u - pi,
+ * cos(2 pi u) = -cos(theta) = sin^2 h - cos^2 h and sin(2 pi u) = -sin(theta)
+ * = -2 sin h cos h.  Absolute error <= 6e-7.  Stands in for the cos/sin of
+ * RayTracing.glsl:69-70 (a GL driver's own approximations) and for the angular
+ * part of utils.h:45. */
 void orc_sincos2pi(float u, float* c_out, float* s_out)
 {
-    float t = u * 4.0f;                 /* exact */
-    int q = (int)t;                     /* quadrant 0..3 */
-    float f = t - (float)q;             /* exact, in [0,1) */
-    float x = f * 0x1.921fb6p+0f;       /* f * pi/2 */
+    float x = fmaf(u, 0x1.921fb6p+1f, -0x1.921fb6p+0f);   /* pi*u - pi/2 */
     float x2 = x * x;
     float ps = -0x1.ae6456p-26f;
     ps = fmaf(ps, x2, 0x1.71de3ap-19f);
@@ -123,20 +143,16 @@ void orc_sincos2pi(float u, float* c_out, float* s_out)
     ps = fmaf(ps, x2, 0x1.111112p-7f);
     ps = fmaf(ps, x2, -0x1.555556p-3f);
     ps = fmaf(ps, x2, 1.0f);
-    float s = x * ps;
+    float s1 = x * ps;
     float pc = 0x1.1eed8ep-29f;
     pc = fmaf(pc, x2, -0x1.27e4fcp-22f);
     pc = fmaf(pc, x2, 0x1.a01a02p-16f);
     pc = fmaf(pc, x2, -0x1.6c16c2p-10f);
     pc = fmaf(pc, x2, 0x1.555556p-5f);
     pc = fmaf(pc, x2, -0.5f);
-    float c = fmaf(pc, x2, 1.0f);
-    switch (q & 3) {
-    case 0: *c_out = c;  *s_out = s;  break;
-    case 1: *c_out = -s; *s_out = c;  break;
-    case 2: *c_out = -c; *s_out = -s; break;
-    default: *c_out = s; *s_out = -c; break;
-    }
+    float c1 = fmaf(pc, x2, 1.0f);
+    *c_out = fmaf(s1, s1, -(c1 * c1));
+    *s_out = (s1 * -2.0f) * c1;
 }
 
 /* randomUnitVector() of utils.h:37-46: a normalised vector of three normal
@@ -212,7 +228,7 @@ float orc_hit_box(const float cc[3], float scale, const float oo[3], const float
         o[k] = inv * (oo[k] - cc[k]);                                /* :141 */
         d[k] = inv * dd[k];                                          /* :142 */
         sg[k] = fsign(o[k]);                                         /* :144 */
-        t[k] = (0.5f - o[k] * sg[k]) / (sg[k] * d[k]);               /* :145 */
+        t[k] = div_nr(0.5f - o[k] * sg[k], sg[k] * d[k]);            /* :145 */
     }
     float best = INFINITY;                                           /* :146 */
     for (int k = 0; k < 3; ++k) {                                    /* :147 */
@@ -231,7 +247,7 @@ void orc_box_normal(const float cc[3], float scale, const float pp[3], float nn[
 {
     float q[3];
     for (int k = 0; k < 3; ++k) {
-        float p = (pp[k] - cc[k]) / scale;                           /* :161 */
+        float p = div_nr(pp[k] - cc[k], scale);                      /* :161 */
         float st = (fabsf(p) < 0.499f) ? 0.0f : 1.0f;                /* step(0.499,|p|) :162 */
         q[k] = st * fsign(p);
     }
@@ -244,7 +260,7 @@ float orc_hit_triangle(const orc_triangle* tr, const float oo[3], const float dd
 {
     v3 a = V(tr->a[0], tr->a[1], tr->a[2]);
     v3 o = V(oo[0], oo[1], oo[2]), d = V(dd[0], dd[1], dd[2]);
-    float k = (tr->beta - dot(a, o)) / dot(a, d);                    /* :181 */
+    float k = div_nr(tr->beta - dot(a, o), dot(a, d));               /* :181 */
     if (k < 0.0f) return INFINITY;                                   /* :182-184 */
     v3 q = vsub(madd(k, d, o), V(tr->position[0], tr->position[1], tr->position[2])); /* :186 */
     float x = dot(q, V(tr->m1[0], tr->m1[1], tr->m1[2]));            /* :187 */

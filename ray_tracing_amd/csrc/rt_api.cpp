@@ -1,8 +1,8 @@
 // rt_api.cpp — the C ABI of include/rt_mi355x.h on top of the HIP kernels.
 //
-// Owns the device copies of the scene (repacked from the reference's 144-byte
-// Shape to the 48-byte DevShape), the accumulator, the running-mean image and
-// the statistics block.  Every HIP return code is checked and turned into an
+// Owns the device copy of the scene (the reference's 144-byte Shapes and 64-byte
+// SimpleTriangles repacked into one blob of 16-byte words, rt_device.h), the
+// accumulator, the running-mean image and the statistics block.  Every HIP return code is checked and turned into an
 // rt_status plus a message; nothing throws across the boundary.  There is no
 // CPU fallback: without a HIP device rt_create fails.
 #include <hip/hip_runtime.h>
@@ -19,8 +19,7 @@
 #include "rt_device.h"
 
 namespace rtd {
-hipError_t launch_trace(int sem, bool stats, bool trace, dim3 grid, hipStream_t stream,
-                        const TraceParams& P, const DevShape* shapes, const DevTriangle* tris,
+hipError_t launch_trace(int sem, int mode, dim3 grid, hipStream_t stream, const TraceParams& P, const void* blob,
                         uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm);
 hipError_t launch_trace_fill(hipStream_t stream, int32_t* hit, uint32_t* mat, size_t n);
 hipError_t launch_resolve(int sem, hipStream_t stream, const uint32_t* accum, float* out, uint32_t w, uint32_t h,
@@ -43,8 +42,12 @@ struct rt_ctx {
     hipStream_t stream = nullptr;
     std::string err;
 
-    rtd::DevShape* d_shapes = nullptr;   uint32_t n_shapes = 0, cap_shapes = 0;
-    rtd::DevTriangle* d_tris = nullptr;  uint32_t n_tris = 0, cap_tris = 0;
+    std::vector<rt_shape> shapes;        // host copies of what was uploaded
+    std::vector<rt_triangle> tris;
+    bool blob_dirty = true;              // the device blob does not reflect them yet
+    void* d_blob = nullptr;              size_t blob_cap = 0;     // bytes
+    rtd::SceneLayout layout{};
+    uint32_t n_spheres = 0, n_boxes = 0;
     float cam[RT_CAMERA_FLOATS] = {};
     bool have_camera = false;
 
@@ -93,6 +96,97 @@ static uint32_t seed_key(uint64_t seed)
     return hash32((uint32_t)seed ^ hash32((uint32_t)(seed >> 32) ^ 0x85ebca6bu));
 }
 
+// The Newton reciprocal of the kernels (rt_kernels.hip, rcp_nr), on the host;
+// this file is compiled with -ffp-contract=off, so it is the same function.
+static float rcp_nr(float x)
+{
+    uint32_t bits; memcpy(&bits, &x, 4);
+    bits = 0x7ef311c7u - bits;
+    float y; memcpy(&y, &bits, 4);
+    for (int k = 0; k < 3; ++k) {
+        float e = std::fmaf(-x, y, 2.0f);
+        y = y * e;
+    }
+    return y;
+}
+
+struct Word { float f[4]; };
+static inline uint32_t& as_u32(float& f) { return reinterpret_cast<uint32_t&>(f); }
+
+// Repack the uploaded arrays into the blob the kernels read (layout: rt_device.h)
+// and copy it to the device.
+static int build_blob(rt_ctx* ctx)
+{
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t n_shapes = (uint32_t)ctx->shapes.size(), n_tris = (uint32_t)ctx->tris.size();
+    uint32_t n_sph = 0, n_box = 0;
+    for (const rt_shape& s : ctx->shapes) { if (s.type == RT_SHAPE_CIRCLE) ++n_sph; else if (s.type == RT_SHAPE_BOX) ++n_box; }
+    rtd::SceneLayout L{};
+    L.n_shapes = n_shapes; L.n_sph_pad = (n_sph + 3u) & ~3u; L.n_box = n_box; L.n_tris = n_tris;
+    L.rec_off = 0;
+    L.sph_off = L.rec_off + 3u * n_shapes;
+    L.sid_off = L.sph_off + L.n_sph_pad;
+    L.box_off = L.sid_off + L.n_sph_pad / 4u;
+    L.tri_off = L.box_off + 2u * n_box;
+    L.total_words = L.tri_off + 4u * n_tris;
+    if ((size_t)L.tri_off * 16u > rtd::LDS_MAX_BYTES)
+        return fail(ctx, RT_ERR_INVALID_ARG, "scene has %u shapes: more than fit the %u-byte LDS stage", n_shapes, rtd::LDS_MAX_BYTES);
+    if ((size_t)L.total_words * 16u <= rtd::LDS_MAX_BYTES) { L.lds_words = L.total_words; L.tri_in_lds = 1; }
+    else { L.lds_words = L.tri_off; L.tri_in_lds = 0; }
+
+    std::vector<Word> blob(L.total_words ? L.total_words : 1u);
+    memset(blob.data(), 0, blob.size() * sizeof(Word));
+    const float nan = std::nanf("");
+    for (uint32_t i = 0; i < L.n_sph_pad; ++i) { Word& w = blob[L.sph_off + i]; w.f[0] = w.f[1] = w.f[2] = nan; w.f[3] = 0.0f; }
+    for (uint32_t i = 0; i < L.n_sph_pad; ++i) as_u32(blob[L.sid_off + i / 4u].f[i % 4u]) = 0xffffffffu;
+    uint32_t is = 0, ib = 0;
+    for (uint32_t i = 0; i < n_shapes; ++i) {
+        const rt_shape& s = ctx->shapes[i];
+        const float cx = s.transformation[12], cy = s.transformation[13], cz = s.transformation[14];
+        const float scale = s.transformation[0];          // radius (shape.h:60) or side (RayTracing.glsl:139)
+        Word& r0 = blob[L.rec_off + 3u * i]; Word& r1 = blob[L.rec_off + 3u * i + 1u]; Word& r2 = blob[L.rec_off + 3u * i + 2u];
+        r0.f[0] = cx; r0.f[1] = cy; r0.f[2] = cz; r0.f[3] = scale;
+        float r = s.material.color[0], g = s.material.color[1], b = s.material.color[2];
+        if (ctx->cfg.semantics == RT_SEM_CPU && s.material.type == RT_MAT_LAMBERTIAN) {
+            // Lambertian::scatter attenuates by 0.6 * albedo (scene.h:56): formed once here.
+            r = r * 0.6f; g = g * 0.6f; b = b * 0.6f;
+        }
+        r1.f[0] = r; r1.f[1] = g; r1.f[2] = b;
+        as_u32(r1.f[3]) = (s.material.type & 0xffffu) | ((s.type & 0xffffu) << 16);
+        r2.f[0] = s.material.data[1];                     // fuzz
+        r2.f[1] = s.material.data[0];                     // ior
+        r2.f[2] = rcp_nr(scale);
+        if (s.type == RT_SHAPE_CIRCLE) {
+            Word& w = blob[L.sph_off + is];
+            w.f[0] = cx; w.f[1] = cy; w.f[2] = cz; w.f[3] = scale * scale;
+            as_u32(blob[L.sid_off + is / 4u].f[is % 4u]) = i;
+            ++is;
+        } else if (s.type == RT_SHAPE_BOX) {
+            Word& w = blob[L.box_off + 2u * ib]; Word& w1 = blob[L.box_off + 2u * ib + 1u];
+            w.f[0] = cx; w.f[1] = cy; w.f[2] = cz; w.f[3] = 1.0f / scale;
+            as_u32(w1.f[0]) = i;
+            ++ib;
+        }
+    }
+    static_assert(sizeof(rt_triangle) == 4 * sizeof(Word), "a SimpleTriangle is four 16-byte words");
+    if (n_tris) memcpy(&blob[L.tri_off], ctx->tris.data(), (size_t)n_tris * sizeof(rt_triangle));
+
+    // The kernels may still be reading the old copy.
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t bytes = blob.size() * sizeof(Word);
+    if (bytes > ctx->blob_cap) {
+        RT_HIP(ctx, hipFree(ctx->d_blob));
+        ctx->d_blob = nullptr; ctx->blob_cap = 0;
+        RT_HIP(ctx, hipMalloc(&ctx->d_blob, bytes));
+        ctx->blob_cap = bytes;
+    }
+    RT_HIP(ctx, hipMemcpy(ctx->d_blob, blob.data(), bytes, hipMemcpyHostToDevice));
+    ctx->layout = L;
+    ctx->n_spheres = n_sph; ctx->n_boxes = n_box;
+    ctx->blob_dirty = false;
+    return RT_OK;
+}
+
 extern "C" {
 
 int rt_create(rt_ctx** out, const rt_config* cfg)
@@ -132,8 +226,7 @@ void rt_destroy(rt_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(ctx->d_shapes);
-    (void)hipFree(ctx->d_tris);
+    (void)hipFree(ctx->d_blob);
     (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_image);
     (void)hipFree(ctx->d_stats);
@@ -153,53 +246,18 @@ int rt_upload_shapes(rt_ctx* ctx, const rt_shape* shapes, uint32_t n)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;
     RT_REQUIRE(ctx, n == 0 || shapes, "rt_upload_shapes: shapes is NULL");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
-    std::vector<rtd::DevShape> packed(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        const rt_shape& s = shapes[i];
-        rtd::DevShape& d = packed[i];
-        d.cx = s.transformation[12]; d.cy = s.transformation[13]; d.cz = s.transformation[14];
-        const float scale = s.transformation[0];
-        d.type = s.type;
-        if (s.type == RT_SHAPE_CIRCLE) { d.p0 = scale * scale; d.p1 = 0.0f; }
-        else { d.p0 = scale; d.p1 = 1.0f / scale; }
-        d.mat_type = s.material.type;
-        d.fuzz = s.material.data[1];
-        d.r = s.material.color[0]; d.g = s.material.color[1]; d.b = s.material.color[2];
-        if (ctx->cfg.semantics == RT_SEM_CPU && s.material.type == RT_MAT_LAMBERTIAN) {
-            // Lambertian::scatter attenuates by 0.6 * albedo (scene.h:56): formed once here.
-            d.r = d.r * 0.6f; d.g = d.g * 0.6f; d.b = d.b * 0.6f;
-        }
-        d.ior = s.material.data[0];
-    }
-    // The kernels may still be reading the old copy.
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (n > ctx->cap_shapes) {
-        RT_HIP(ctx, hipFree(ctx->d_shapes));
-        ctx->d_shapes = nullptr; ctx->cap_shapes = 0;
-        RT_HIP(ctx, hipMalloc(&ctx->d_shapes, sizeof(rtd::DevShape) * n));
-        ctx->cap_shapes = n;
-    }
-    if (n) RT_HIP(ctx, hipMemcpy(ctx->d_shapes, packed.data(), sizeof(rtd::DevShape) * n, hipMemcpyHostToDevice));
-    ctx->n_shapes = n;
-    return RT_OK;
+    try { ctx->shapes.assign(shapes, shapes + n); } catch (...) { return fail(ctx, RT_ERR_OUT_OF_MEMORY, "rt_upload_shapes: host allocation failed"); }
+    ctx->blob_dirty = true;
+    return build_blob(ctx);
 }
 
 int rt_upload_triangles(rt_ctx* ctx, const rt_triangle* tris, uint32_t n)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;
     RT_REQUIRE(ctx, n == 0 || tris, "rt_upload_triangles: triangles is NULL");
-    RT_HIP(ctx, hipSetDevice(ctx->device));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (n > ctx->cap_tris) {
-        RT_HIP(ctx, hipFree(ctx->d_tris));
-        ctx->d_tris = nullptr; ctx->cap_tris = 0;
-        RT_HIP(ctx, hipMalloc(&ctx->d_tris, sizeof(rtd::DevTriangle) * n));
-        ctx->cap_tris = n;
-    }
-    if (n) RT_HIP(ctx, hipMemcpy(ctx->d_tris, tris, sizeof(rtd::DevTriangle) * n, hipMemcpyHostToDevice));
-    ctx->n_tris = n;
-    return RT_OK;
+    try { ctx->tris.assign(tris, tris + n); } catch (...) { return fail(ctx, RT_ERR_OUT_OF_MEMORY, "rt_upload_triangles: host allocation failed"); }
+    ctx->blob_dirty = true;
+    return build_blob(ctx);
 }
 
 int rt_set_camera(rt_ctx* ctx, const float data[RT_CAMERA_FLOATS])
@@ -289,7 +347,7 @@ static int fill_params(rt_ctx* ctx, rtd::TraceParams& P, uint32_t width, uint32_
     for (int k = 0; k < 3; ++k)     // triangles are Lambertian (glsl:275); CPU rules attenuate by 0.6 * albedo (scene.h:56)
         P.tri_albedo[k] = ctx->cfg.semantics == RT_SEM_CPU ? ctx->cfg.triangle_albedo[k] * 0.6f : ctx->cfg.triangle_albedo[k];
     P.width = width; P.height = height;
-    P.n_shapes = ctx->n_shapes; P.n_tris = ctx->n_tris;
+    P.scene = ctx->layout;
     P.spp = spp; P.first_sample = first_sample; P.max_depth = max_depth;
     P.seed_key = seed_key(seed);
     P.sample_mode = ctx->cfg.sample_mode; P.flags = ctx->cfg.flags;
@@ -323,9 +381,10 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
     rc = ensure_accum(ctx, width, height);
     if (rc) return rc;
     if (stats) RT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * rtd::ST_COUNT, ctx->stream));
+    if (ctx->blob_dirty) { rc = build_blob(ctx); if (rc) return rc; }
     if (spp > 0 && P.owned_rows > 0) {
-        RT_HIP(ctx, rtd::launch_trace((int)ctx->cfg.semantics, stats != nullptr, false, trace_grid(P), ctx->stream, P,
-                                      ctx->d_shapes, ctx->d_tris, accum_ptr(ctx), ctx->d_stats, nullptr, nullptr));
+        RT_HIP(ctx, rtd::launch_trace((int)ctx->cfg.semantics, stats ? 1 : 0, trace_grid(P), ctx->stream, P,
+                                      ctx->d_blob, accum_ptr(ctx), ctx->d_stats, nullptr, nullptr));
     }
     ctx->accum_samples += spp;
     if (stats) {
@@ -338,16 +397,10 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         stats->terminal = h[rtd::ST_TERMINAL];
         // Every segment tests every primitive (the reference's closest-hit
         // loops are exhaustive), so the test counts follow from the segments.
-        uint64_t n_sph = 0, n_box = 0;
-        if (ctx->n_shapes) {
-            std::vector<rtd::DevShape> host(ctx->n_shapes);
-            RT_HIP(ctx, hipMemcpy(host.data(), ctx->d_shapes, sizeof(rtd::DevShape) * ctx->n_shapes, hipMemcpyDeviceToHost));
-            for (const auto& s : host) { if (s.type == RT_SHAPE_CIRCLE) ++n_sph; else if (s.type == RT_SHAPE_BOX) ++n_box; }
-        }
-        stats->shape_tests = stats->segments * ctx->n_shapes;
-        stats->sphere_tests = stats->segments * n_sph;
-        stats->box_tests = stats->segments * n_box;
-        stats->triangle_tests = stats->segments * ctx->n_tris;
+        stats->shape_tests = stats->segments * ctx->shapes.size();
+        stats->sphere_tests = stats->segments * ctx->n_spheres;
+        stats->box_tests = stats->segments * ctx->n_boxes;
+        stats->triangle_tests = stats->segments * ctx->tris.size();
     }
     return RT_OK;
 }
@@ -473,7 +526,7 @@ int rt_trace_debug(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t max_de
     e = rtd::launch_trace_fill(ctx->stream, d_hit, d_mat, n);
     // accum is not touched by a TRACE launch; pass any valid pointer.
     if (e == hipSuccess)
-        e = rtd::launch_trace((int)ctx->cfg.semantics, false, true, trace_grid(P), ctx->stream, P, ctx->d_shapes, ctx->d_tris,
+        e = rtd::launch_trace((int)ctx->cfg.semantics, 2, trace_grid(P), ctx->stream, P, ctx->d_blob,
                               reinterpret_cast<uint32_t*>(d_hit), ctx->d_stats, d_hit, d_mat);
     if (e == hipSuccess) e = hipMemcpyAsync(hit_index_host, d_hit, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(material_id_host, d_mat, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);

@@ -4,52 +4,59 @@
 
 namespace rtd {
 
-// One shape as the kernels read it: 48 bytes, three 16-byte words, repacked
-// from the 144-byte Shape of the reference (src/gpu_version/shape.h:44-54) at
-// upload time.  The closest-hit loop reads word 0 and 1 with wave-uniform
-// (scalar) loads; after the loop each lane reads the record it hit.
-struct alignas(16) DevShape {
-    float    cx, cy, cz;   // translation: transformation column 3
-    float    p0;           // Circle: radius*radius.  Box: side (transformation[0][0])
-    float    p1;           // Box: 1.0f / side
-    uint32_t type;         // 0 Circle, 1 Box
-    uint32_t mat_type;     // 0 Light, 1 Lambertian, 2 Metal, 3 Dielectric, 100 Debug
-    float    fuzz;         // material.data[1]
-    float    r, g, b;      // material.color
-    float    ior;          // material.data[0]
+// The scene as the kernels read it: ONE contiguous array of 16-byte words
+// ("blob") in device memory, built at upload time from the reference's
+// 144-byte Shape (src/gpu_version/shape.h:44-54) and 64-byte SimpleTriangle
+// (shape.h:103-108) arrays.  Every workgroup copies the first `lds_words`
+// words into LDS before tracing and addresses them there; what does not fit
+// (a mesh larger than the LDS budget) is read from the blob in global memory
+// with wave-uniform addresses.
+//
+//   rec  [3 * n_shapes]   per shape, by the shape's index in the uploaded array:
+//                           word 0: centre.xyz, scale (Circle: radius, Box: side)
+//                           word 1: colour.rgb (x 0.6 for Lambertian under CPU rules), tag
+//                                   tag = material type | shape type << 16
+//                           word 2: fuzz, ior, rcp_nr(scale), unused
+//   sph  [n_sph_pad]      spheres in upload order: centre.xyz, radius^2; padded to a
+//                         multiple of 4 with NaN centres (never hit)
+//   sid  [n_sph_pad / 4]  the spheres' shape indices, four per word
+//   box  [2 * n_box]      boxes in upload order: {centre.xyz, 1/side}, {shape index, 0, 0, 0}
+//   tri  [4 * n_tris]     SimpleTriangle as uploaded: {position}, {a.xyz, beta}, {m1}, {m2}
+struct SceneLayout {
+    uint32_t n_shapes, n_sph_pad, n_box, n_tris;
+    uint32_t rec_off, sph_off, sid_off, box_off, tri_off;   // in 16-byte words
+    uint32_t total_words;                                   // whole blob
+    uint32_t lds_words;                                     // prefix staged in LDS
+    uint32_t tri_in_lds;                                    // 1 if the triangles are part of that prefix
 };
-static_assert(sizeof(DevShape) == 48, "DevShape must be three 16-byte words");
 
-// A triangle keeps the reference's 64-byte SimpleTriangle layout
-// (src/gpu_version/shape.h:103-108): position.xyz _, a.xyz beta, m1.xyz _, m2.xyz _.
-struct alignas(16) DevTriangle {
-    float px, py, pz, pw;
-    float ax, ay, az, beta;
-    float m1x, m1y, m1z, m1w;
-    float m2x, m2y, m2z, m2w;
-};
-static_assert(sizeof(DevTriangle) == 64, "DevTriangle must match SimpleTriangle");
-
-// Everything one trace launch needs besides the scene arrays; passed by value
-// in the kernel-argument segment, so every field is read with scalar loads.
+// Everything one trace launch needs besides the blob; passed by value in the
+// kernel-argument segment.
 struct TraceParams {
     float    cam[21];          // Camera::data (src/gpu_version/camera.h:117)
     float    tri_albedo[3];
     uint32_t width, height;
-    uint32_t n_shapes, n_tris;
     uint32_t spp, first_sample, max_depth, grid_n;
     uint32_t seed_key;         // hash of the 64-bit seed
     uint32_t sample_mode, flags;
     uint32_t shard_index, shard_count, band_rows;
     uint32_t owned_rows;       // rows of this shard
     uint32_t trace_sample;     // TRACE launches: the one sample to follow
+    SceneLayout scene;
 };
 
 // Slots of the statistics block (uint64 each).
 enum { ST_SAMPLES = 0, ST_SEGMENTS, ST_DIFFUSE, ST_SPECULAR, ST_TERMINAL, ST_COUNT };
 
-constexpr int TILE_W = 8;      // pixels per workgroup in x (two 8-wide wave tiles)
-constexpr int TILE_H = 8;      // and in y
-constexpr int BLOCK = 64;
+constexpr int TILE_W = 16;     // pixels per workgroup in x (two 8-wide wave tiles)
+constexpr int TILE_H = 16;     // and in y
+constexpr int BLOCK = 256;
+
+// LDS a workgroup may use for the staged scene.  8 workgroups of 4 waves fill a
+// CU's 32 wave slots; 160 KiB / 8 = 20 KiB each keeps that occupancy.  Scenes
+// up to LDS_MAX_BYTES are still staged (fewer workgroups per CU); beyond it the
+// triangles stay in global memory.
+constexpr uint32_t LDS_FULL_OCCUPANCY_BYTES = 20u * 1024u;
+constexpr uint32_t LDS_MAX_BYTES = 64u * 1024u;
 
 }  // namespace rtd

@@ -11,18 +11,21 @@
 // next sample in the same loop iteration in which its neighbours trace a
 // bounce: lanes never wait for the longest path of a sample.
 //
-// The scene is read-only and tiny next to the caches; every lane tests the
-// same primitive at the same time, so the closest-hit loops address it with a
-// wave-uniform index and the compiler fetches it through the scalar data path
-// into SGPRs (s_load_dwordx4/x8/x16).  Nothing is staged in VGPRs or LDS for
-// the loops; only the record of the primitive a lane finally hit is fetched
-// per lane.
+// Scene data: every workgroup first copies the scene blob (rt_device.h) into
+// LDS.  The closest-hit loops read it from there with wave-uniform addresses
+// (every lane tests the same primitive at the same time; identical LDS
+// addresses broadcast), which puts the primitive in VECTOR registers: on this
+// chip a vector instruction with a scalar-register operand issues at half the
+// rate of one whose operands are all vector registers, so the scene is kept
+// out of the scalar file on purpose.  The record of the primitive a lane
+// finally hit is gathered per lane, also from LDS.
 //
 // Arithmetic: binary32 throughout, compiled with -ffp-contract=off.  Every
-// fused multiply-add is an explicit __builtin_fmaf; division and sqrtf are the
-// correctly rounded forms (hipcc default).  No OCML sin/cos/log: the samplers
-// use the polynomial below.  With that, every value computed here can be
-// reproduced bit for bit by scalar IEEE-754 code on a CPU.
+// fused multiply-add is an explicit __builtin_fmaf; sqrt is correctly rounded
+// (v_sqrt_f32 plus a residual test); reciprocal square root and reciprocal are
+// fixed Newton recipes; sin/cos a fixed polynomial.  No OCML function feeds
+// geometry.  With that, every value computed here can be reproduced bit for
+// bit by scalar IEEE-754 code on a CPU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "rt_device.h"
@@ -41,6 +44,7 @@ RT_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 RT_DEV float dot(V3 a, V3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 // o + t*d
 RT_DEV V3 madd(float t, V3 d, V3 o) { return v3(fma_(t, d.x, o.x), fma_(t, d.y, o.y), fma_(t, d.z, o.z)); }
+RT_DEV V3 xyz(float4 v) { return v3(v.x, v.y, v.z); }
 // 1/sqrt(q): bit-trick first guess + three Newton steps, every step an IEEE
 // operation (relative error <= 1.3e-7).  A third of the issue slots of a
 // correctly rounded sqrt followed by a correctly rounded divide, and — unlike
@@ -58,14 +62,26 @@ RT_DEV float rsqrt_nr(float q)
     return y;
 }
 RT_DEV V3 normalize(V3 v) { return v * rsqrt_nr(dot(v, v)); }
+// 1/x the same way: y <- y * (2 - x*y), three times (relative error <= 1.2e-7).
+// a / b of the shader's routines (RayTracing.glsl:145,161,181) is a * rcp_nr(b):
+// GLSL specifies its division to 2.5 ulp only, and the correctly rounded
+// divide costs about 42 issue cycles here against 19.
+RT_DEV float rcp_nr(float x)
+{
+    float y = __uint_as_float(0x7ef311c7u - __float_as_uint(x));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float e = fma_(-x, y, 2.0f);
+        y = y * e;
+    }
+    return y;
+}
 // Correctly rounded sqrt: v_sqrt_f32 (within 1 ulp) plus a residual test against each
-// neighbour — the sequence hipcc emits for sqrtf, without its range scaling.  Arguments in
-// (0, 2^-96), where the residuals would go subnormal, take the compiler's general sequence
-// when GUARD is set; callers whose argument cannot be that small pass GUARD = false.
-template <bool GUARD>
+// neighbour — the sequence hipcc emits for sqrtf, without its range scaling.  For
+// arguments in (0, 2^-96), where the residuals go subnormal, the result is only a
+// tiny number of the right order; every caller below tolerates that (see them).
 RT_DEV float sqrt_rn(float x)
 {
-    if (GUARD && __builtin_expect(__any((__float_as_uint(x) - 1u) < 0x0f7fffffu), 0)) return __builtin_sqrtf(x);
     float s = __builtin_amdgcn_sqrtf(x);
     float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
     float rm = fma_(-sm, s, x), rp = fma_(-sp, s, x);
@@ -101,14 +117,13 @@ RT_DEV float draw(uint32_t key, uint32_t index)
 // Draws 0,1: sub-pixel jitter.  Bounce b: draws 2+4b .. 5+4b.
 RT_DEV uint32_t bounce_draw(uint32_t bounce) { return 2u + 4u * bounce; }
 
-// cos(2 pi u), sin(2 pi u), u in [0,1): quadrant split (exact) and Taylor
-// polynomials on [0, pi/2) in Horner form.
+// cos(2 pi u), sin(2 pi u), u in [0,1), without a quadrant case split: the half
+// angle h = pi*u - pi/2 lies in [-pi/2, pi/2), where one odd and one even Taylor
+// polynomial (Horner form) give sin h and cos h; then cos(2 pi u) = sin^2 h -
+// cos^2 h and sin(2 pi u) = -2 sin h cos h.
 RT_DEV void sincos2pi(float u, float& c_out, float& s_out)
 {
-    float t = u * 4.0f;
-    int q = (int)t;
-    float f = t - (float)q;
-    float x = f * 0x1.921fb6p+0f;
+    float x = fma_(u, 0x1.921fb6p+1f, -0x1.921fb6p+0f);
     float x2 = x * x;
     float ps = -0x1.ae6456p-26f;
     ps = fma_(ps, x2, 0x1.71de3ap-19f);
@@ -116,19 +131,16 @@ RT_DEV void sincos2pi(float u, float& c_out, float& s_out)
     ps = fma_(ps, x2, 0x1.111112p-7f);
     ps = fma_(ps, x2, -0x1.555556p-3f);
     ps = fma_(ps, x2, 1.0f);
-    float s = x * ps;
+    float s1 = x * ps;
     float pc = 0x1.1eed8ep-29f;
     pc = fma_(pc, x2, -0x1.27e4fcp-22f);
     pc = fma_(pc, x2, 0x1.a01a02p-16f);
     pc = fma_(pc, x2, -0x1.6c16c2p-10f);
     pc = fma_(pc, x2, 0x1.555556p-5f);
     pc = fma_(pc, x2, -0.5f);
-    float c = fma_(pc, x2, 1.0f);
-    // q: 0 (c,s)  1 (-s,c)  2 (-c,-s)  3 (s,-c)
-    float a = (q & 1) ? s : c;
-    float b = (q & 1) ? c : s;
-    c_out = ((q + 1) & 2) ? -a : a;
-    s_out = (q & 2) ? -b : b;
+    float c1 = fma_(pc, x2, 1.0f);
+    c_out = fma_(s1, s1, -(c1 * c1));
+    s_out = (s1 * -2.0f) * c1;
 }
 
 // A point uniform on the unit sphere: what randomUnitVector() of
@@ -136,7 +148,7 @@ RT_DEV void sincos2pi(float u, float& c_out, float& s_out)
 RT_DEV V3 unit_vector(float u1, float u2)
 {
     float z = fma_(-2.0f, u1, 1.0f);
-    float r = sqrt_rn<false>(fma_(-z, z, 1.0f));     // 1 - z*z is 0 or >= 2^-23
+    float r = sqrt_rn(fma_(-z, z, 1.0f));            // 1 - z*z is 0 or >= 2^-23
     float c, s;
     sincos2pi(u2, c, s);
     return v3(r * c, r * s, z);
@@ -148,10 +160,11 @@ RT_DEV V3 hemisphere_glsl(V3 n, float u1, float u2)
     float c, s;
     sincos2pi(u1, c, s);
     float r = u2;
-    float dist = sqrt_rn<false>(fma_(-r, r, 1.0f));  // 1 - r*r >= 2^-24
+    float dist = sqrt_rn(fma_(-r, r, 1.0f));         // 1 - r*r >= 2^-24
     float x = c * dist, y = s * dist;
     float q = fma_(n.x, n.x, n.y * n.y);          // |(-n.y, n.x, 0)|^2
-    float len_xy = sqrt_rn<true>(q);
+    // The length is only compared with 0.01: any tiny value serves for a tiny q.
+    float len_xy = sqrt_rn(q);
     V3 b1;
     if (len_xy < 0.01f) b1 = normalize(v3(0.0f, -n.z, n.y));
     else { float inv = rsqrt_nr(q); b1 = v3(-n.y * inv, n.x * inv, 0.0f * inv); }
@@ -162,31 +175,53 @@ RT_DEV V3 hemisphere_glsl(V3 n, float u1, float u2)
 }
 
 // ---------------------------------------------------------- intersection
+// A hit distance t lies in the acceptance window and is closer than the best
+// so far exactly when  bits(t) - TMIN  <  bits(best) - TMIN  as unsigned
+// integers, TMIN being the bit pattern of the window's first accepted value:
+// positive floats order like their bit patterns, and anything below the window,
+// negative, infinite or NaN wraps to a number above every possible right-hand
+// side.  One integer compare stands for the window's two tests and the `<` of
+// the closest-hit loop (scene.h:237 with rayTracer.h:117; RayTracing.glsl:212).
+//   CPU tracer: 0.001 < t (double against widened float: true exactly from
+//               0.001f on) and t < FLT_MAX.
+//   Shader:     0.0001 < t < 1000.
+template <int SEM> struct Window;
+template <> struct Window<0> { static constexpr uint32_t tmin = 0x3a83126fu, far = 0x7f7fffffu; };   // 0.001f, FLT_MAX
+template <> struct Window<1> { static constexpr uint32_t tmin = 0x38d1b718u, far = 0x447a0000u; };   // next above 0.0001f, 1000.0f
+
 // Sphere::hit (src/cpu_version/scene.h:115-128) = hitSphere
-// (RayTracing.glsl:118-132).  r2 = radius*radius, formed at upload.
-RT_DEV float hit_sphere(float cx, float cy, float cz, float r2, V3 o, V3 d)
+// (RayTracing.glsl:118-132).  s = centre.xyz, radius^2.
+template <int SEM>
+RT_DEV void test_sphere(float4 s, uint32_t shape_id, V3 o, V3 d, uint32_t& best_key, uint32_t& best_id)
 {
-    V3 oc = v3(o.x - cx, o.y - cy, o.z - cz);
+    V3 oc = v3(o.x - s.x, o.y - s.y, o.z - s.z);
     float b = dot(oc, d);
-    float c = fma_(oc.z, oc.z, fma_(oc.y, oc.y, fma_(oc.x, oc.x, -r2)));   // oc.oc - r*r
+    float c = fma_(oc.z, oc.z, fma_(oc.y, oc.y, fma_(oc.x, oc.x, -s.w)));   // oc.oc - r*r
     float disc = fma_(b, b, -c);
     // The root -b - sqrt(disc) can only lie in the window (t > 0) when b < 0 and disc >= 0.
-    // When that holds for no lane of the wave the square root is skipped; the NaN returned
-    // instead fails every comparison, exactly as the skipped value would have.
-    if (!__any(b < 0.0f && disc >= 0.0f)) return __builtin_nanf("");
-    return -b - sqrt_rn<true>(disc);       // disc < 0 gives NaN, which every later comparison rejects
+    // When that holds for no lane of the wave the square root is skipped.  Where it holds
+    // for some lanes only, the others produce a NaN or a non-positive t, which the key
+    // test rejects.  (A disc below 2^-96 makes the root irrelevant: t is then -b to the
+    // last bit, or lies below the window.)
+    if (!__any(b < 0.0f && disc >= 0.0f)) return;
+    float t = -b - sqrt_rn(disc);
+    uint32_t key = __float_as_uint(t) - Window<SEM>::tmin;
+    bool take = key < best_key;
+    best_key = take ? key : best_key;
+    best_id = take ? shape_id : best_id;
 }
 
-// hitBox, RayTracing.glsl:138-156.
-RT_DEV float hit_box(float cx, float cy, float cz, float inv, V3 o, V3 d)
+// hitBox, RayTracing.glsl:138-156.  bx = centre.xyz, 1/side.
+RT_DEV float hit_box(float4 bx, V3 o, V3 d)
 {
-    V3 ob = v3(inv * (o.x - cx), inv * (o.y - cy), inv * (o.z - cz));
+    const float inv = bx.w;
+    V3 ob = v3(inv * (o.x - bx.x), inv * (o.y - bx.y), inv * (o.z - bx.z));
     V3 db = v3(inv * d.x, inv * d.y, inv * d.z);
     V3 sg = v3(sign_(ob.x), sign_(ob.y), sign_(ob.z));
     float t[3];
-    t[0] = (0.5f - ob.x * sg.x) / (sg.x * db.x);
-    t[1] = (0.5f - ob.y * sg.y) / (sg.y * db.y);
-    t[2] = (0.5f - ob.z * sg.z) / (sg.z * db.z);
+    t[0] = (0.5f - ob.x * sg.x) * rcp_nr(sg.x * db.x);
+    t[1] = (0.5f - ob.y * sg.y) * rcp_nr(sg.y * db.y);
+    t[2] = (0.5f - ob.z * sg.z) * rcp_nr(sg.z * db.z);
     float best = __builtin_inff();
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -199,36 +234,33 @@ RT_DEV float hit_box(float cx, float cy, float cz, float inv, V3 o, V3 d)
     return best;
 }
 
-// boxNormalAt, RayTracing.glsl:158-163.
-RT_DEV V3 box_normal(float cx, float cy, float cz, float scale, V3 p)
+// boxNormalAt, RayTracing.glsl:158-163.  c = centre, rs = rcp_nr(side).
+RT_DEV V3 box_normal(V3 c, float rs, V3 p)
 {
-    float qx = (p.x - cx) / scale, qy = (p.y - cy) / scale, qz = (p.z - cz) / scale;
+    float qx = (p.x - c.x) * rs, qy = (p.y - c.y) * rs, qz = (p.z - c.z) * rs;
     V3 n = v3(((__builtin_fabsf(qx) < 0.499f) ? 0.0f : 1.0f) * sign_(qx),
               ((__builtin_fabsf(qy) < 0.499f) ? 0.0f : 1.0f) * sign_(qy),
               ((__builtin_fabsf(qz) < 0.499f) ? 0.0f : 1.0f) * sign_(qz));
     return normalize(n);
 }
 
-// hitTriangle, RayTracing.glsl:179-194.
-RT_DEV float hit_triangle(const DevTriangle& tr, V3 o, V3 d)
-{
-    V3 a = v3(tr.ax, tr.ay, tr.az);
-    float k = (tr.beta - dot(a, o)) / dot(a, d);
-    V3 p = madd(k, d, o);
-    V3 q = v3(p.x - tr.px, p.y - tr.py, p.z - tr.pz);
-    float x = dot(q, v3(tr.m1x, tr.m1y, tr.m1z));
-    float y = dot(q, v3(tr.m2x, tr.m2y, tr.m2z));
-    bool hit = !(k < 0.0f) && x > 0.0f && y > 0.0f && (x + y) < 1.0f;
-    return hit ? k : __builtin_inff();
-}
-
-// Acceptance window of a hit distance.  CPU tracer: scene.h:237 with the
-// arguments of rayTracer.h:117 (t_min is the double 0.001 compared with a
-// widened float, true exactly when t >= 0.001f).  Shader: RayTracing.glsl:212.
+// hitTriangle, RayTracing.glsl:179-194, on the four words of a SimpleTriangle.
+// The early return for k < 0 (:182-184) is left to the window test, which
+// rejects every negative k.
 template <int SEM>
-RT_DEV bool in_window_near(float t)
+RT_DEV void test_triangle(float4 w0, float4 w1, float4 w2, float4 w3, uint32_t id, V3 o, V3 d,
+                          uint32_t& best_key, uint32_t& best_id)
 {
-    return (SEM == 0) ? (t >= 0.001f) : (t > 0.0001f);
+    V3 a = xyz(w1);
+    float k = (w1.w - dot(a, o)) * rcp_nr(dot(a, d));
+    V3 p = madd(k, d, o);
+    V3 q = v3(p.x - w0.x, p.y - w0.y, p.z - w0.z);
+    float x = dot(q, xyz(w2));
+    float y = dot(q, xyz(w3));
+    uint32_t key = __float_as_uint(k) - Window<SEM>::tmin;
+    bool take = x > 0.0f && y > 0.0f && (x + y) < 1.0f && key < best_key;
+    best_key = take ? key : best_key;
+    best_id = take ? id : best_id;
 }
 
 // uvec4(255 * color), RayTracing.glsl:301; negative and NaN give 0, large
@@ -242,27 +274,34 @@ RT_DEV uint32_t quantise(float c)
 // -------------------------------------------------------------- the tracer
 // SEM 0: rules of src/cpu_version (rayTracer.h:110-132, scene.h:39-109).
 // SEM 1: rules of RayTracing.glsl:233-288.
-// STATS: count work.  TRACE: follow one sample, record hit and material ids,
-// leave the accumulator alone.
+// TRI_GLOBAL: the triangles did not fit into LDS and are read from the blob in
+// global memory.  MODE 0: render.  MODE 1: render and count work.  MODE 2:
+// follow one sample, record hit and material ids, leave the accumulator alone.
 //
 // One loop iteration = one ray segment of every live lane: closest hit, then
 // the surface event.  Lanes whose path ended start their next sample in the
 // same iteration, and the two expensive steps every continuing lane needs —
 // two random draws and the normalisation of the new direction — are issued
 // once for the whole wave, whether a lane is bouncing or starting a sample.
-template <int SEM, bool STATS, bool TRACE>
+template <int SEM, bool TRI_GLOBAL, int MODE>
 __global__ __launch_bounds__(BLOCK)
 void trace_kernel(const TraceParams P,
-                  const DevShape* __restrict__ shapes,
-                  const DevTriangle* __restrict__ tris,
+                  const float4* __restrict__ blob,
                   uint32_t* __restrict__ accum,
                   unsigned long long* __restrict__ stats,
                   int32_t* __restrict__ trace_hit,
                   uint32_t* __restrict__ trace_mat)
 {
+    constexpr bool STATS = MODE == 1, TRACE = MODE == 2;
+    extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < P.scene.lds_words; i += BLOCK) lds[i] = blob[i];
+    __syncthreads();
+
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     const uint32_t gx = blockIdx.x * TILE_W + (wave & 1u) * 8u + (lane & 7u);
+    // Workgroups are handed out in blockIdx order; the bottom rows of a frame
+    // (ground, objects: long paths) go first, the top rows (sky) fill the tail.
     const uint32_t row = (gridDim.y - 1u - blockIdx.y) * TILE_H + (wave >> 1) * 8u + (lane >> 3);   // ordinal among owned rows
     const uint32_t band = row / P.band_rows;
     const uint32_t gy = (band * P.shard_count + P.shard_index) * P.band_rows + (row - band * P.band_rows);
@@ -291,9 +330,8 @@ void trace_kernel(const TraceParams P,
     const uint32_t sample_end = TRACE ? P.trace_sample + 1u : P.first_sample + P.spp;
     bool alive = valid && sample < sample_end;
 
-    // Origin and un-normalised direction of the camera ray of `sample`:
-    // RayTracing.glsl:296-297 (jitter, from two draws) or renderPixel<N>,
-    // src/cpu_version/rayTracer.h:92-101 (grid).
+    // Origin of the camera ray of `sample`: RayTracing.glsl:296 (jitter, from
+    // two draws) or renderPixel<N>, src/cpu_version/rayTracer.h:92-101 (grid).
     auto camera_origin = [&](uint32_t smp, float u1, float u2) -> V3 {
         if (P.sample_mode == 0u) {
             float s1 = step * u1, s2 = step * u2;
@@ -325,59 +363,77 @@ void trace_kernel(const TraceParams P,
         if (STATS) ++n_samples;
     }
 
-    const uint32_t n_shapes = P.n_shapes, n_tris = P.n_tris;
-    const float t_far = (SEM == 0) ? 3.402823466e+38f : 1000.0f;   // scene.h:237 / glsl:212
+    const SceneLayout& L = P.scene;
+    const float4* const sph = lds + L.sph_off;
+    const float4* const sid = lds + L.sid_off;
+    const float4* const box = lds + L.box_off;
+    const float4* const rec = lds + L.rec_off;
+    const float4* const tri = TRI_GLOBAL ? blob + L.tri_off : lds + L.tri_off;
+    const uint32_t n_chunks = L.n_sph_pad >> 2, n_box = L.n_box, n_tris = L.n_tris, n_shapes = L.n_shapes;
+    constexpr uint32_t NONE = 0xffffffffu;
 
     while (alive) {
         // ---- closest hit: Scene::hit (scene.h:232-255) /
         //      getClosestShapeIndex + getClosestTriangleIndex (glsl:206-231).
-        //      `best` starts at the far end of the window, so `t < best`
-        //      also is the window's upper test; a NaN t fails both tests.
-        float best = t_far;
-        int index = -1;
-        for (uint32_t i = 0; i < n_shapes; ++i) {
-            const DevShape& s = shapes[i];
-            float t;
-            if (s.type == 0u) t = hit_sphere(s.cx, s.cy, s.cz, s.p0, o, d);
-            else if (s.type == 1u) t = hit_box(s.cx, s.cy, s.cz, s.p1, o, d);
-            else t = -1.0f;
-            if (in_window_near<SEM>(t) && t < best) { best = t; index = (int)i; }
+        //      One running (key, id) serves shapes and triangles: shapes come first
+        //      and every replacement needs a strictly smaller distance, so a
+        //      triangle wins only when strictly closer than the closest shape
+        //      (glsl:271) and the first of equal distances stays.
+        uint32_t best_key = Window<SEM>::far - Window<SEM>::tmin;
+        uint32_t best_id = NONE;
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            const float4 s0 = sph[4u * c], s1 = sph[4u * c + 1u], s2 = sph[4u * c + 2u], s3 = sph[4u * c + 3u];
+            const float4 ids = sid[c];
+            test_sphere<SEM>(s0, __float_as_uint(ids.x), o, d, best_key, best_id);
+            test_sphere<SEM>(s1, __float_as_uint(ids.y), o, d, best_key, best_id);
+            test_sphere<SEM>(s2, __float_as_uint(ids.z), o, d, best_key, best_id);
+            test_sphere<SEM>(s3, __float_as_uint(ids.w), o, d, best_key, best_id);
         }
-        float best_tri = t_far;
-        int index_tri = -1;
+        for (uint32_t i = 0; i < n_box; ++i) {
+            const float4 bx = box[2u * i];
+            const uint32_t bid = __float_as_uint(box[2u * i + 1u].x);
+            float t = hit_box(bx, o, d);
+            uint32_t k = __float_as_uint(t) - Window<SEM>::tmin;
+            // Spheres were scanned before boxes whatever their place in the uploaded
+            // array: at equal distance the lower shape index wins, as it would have
+            // in the reference's single scan.
+            bool take = k < best_key || (k == best_key && best_id != NONE && bid < best_id);
+            best_key = take ? k : best_key;
+            best_id = take ? bid : best_id;
+        }
         for (uint32_t i = 0; i < n_tris; ++i) {
-            float t = hit_triangle(tris[i], o, d);
-            if (in_window_near<SEM>(t) && t < best_tri) { best_tri = t; index_tri = (int)i; }
+            const float4 w0 = tri[4u * i], w1 = tri[4u * i + 1u], w2 = tri[4u * i + 2u], w3 = tri[4u * i + 3u];
+            test_triangle<SEM>(w0, w1, w2, w3, n_shapes + i, o, d, best_key, best_id);
         }
         if (STATS) ++n_segments;
 
         // ---- the surface
-        uint32_t type = 0xffffffffu;           // nothing hit
-        int hit_id = -1;
+        uint32_t type = NONE;                  // nothing hit
         V3 n = v3(0, 0, 0), att = v3(0, 0, 0);
         float fuzz = 0.0f;
-        const bool is_tri = index_tri >= 0 && best_tri < best;        // glsl:271
-        const V3 p = madd(is_tri ? best_tri : best, d, o);            // Ray::at / glsl:239
-        if (is_tri) {
-            const DevTriangle& tr = tris[index_tri];
-            V3 a = v3(tr.ax, tr.ay, tr.az);
-            n = a * sign_(-dot(d, a));                                // glsl:165-167,272
-            att = v3(P.tri_albedo[0], P.tri_albedo[1], P.tri_albedo[2]);
-            type = 1u;
-            hit_id = (int)n_shapes + index_tri;
-        } else if (index >= 0) {
-            const DevShape s = shapes[index];
-            if (s.type == 0u) n = normalize(v3(p.x - s.cx, p.y - s.cy, p.z - s.cz));     // scene.h:130-132
-            else if (s.type == 1u) n = box_normal(s.cx, s.cy, s.cz, s.p0, p);
-            else n = v3(1.0f, 1.0f, 1.0f);                            // glsl:203
-            att = v3(s.r, s.g, s.b);
-            type = s.mat_type;
-            fuzz = s.fuzz;
-            hit_id = index;
+        const float t_hit = __uint_as_float(best_key + Window<SEM>::tmin);
+        const V3 p = madd(t_hit, d, o);                               // Ray::at / glsl:239
+        if (best_id != NONE) {
+            if (best_id >= n_shapes) {
+                V3 a = xyz(tri[4u * (best_id - n_shapes) + 1u]);
+                n = a * sign_(-dot(d, a));                            // glsl:165-167,272
+                att = v3(P.tri_albedo[0], P.tri_albedo[1], P.tri_albedo[2]);
+                type = 1u;
+            } else {
+                const float4 r0 = rec[3u * best_id], r1 = rec[3u * best_id + 1u];
+                const uint32_t tag = __float_as_uint(r1.w);
+                const uint32_t stype = tag >> 16;
+                type = tag & 0xffffu;
+                att = xyz(r1);
+                if (stype == 0u) n = normalize(v3(p.x - r0.x, p.y - r0.y, p.z - r0.z));      // scene.h:130-132
+                else if (stype == 1u) n = box_normal(xyz(r0), rec[3u * best_id + 2u].z, p);
+                else n = v3(1.0f, 1.0f, 1.0f);                        // glsl:203
+                if (SEM == 0 && type == 2u) fuzz = rec[3u * best_id + 2u].x;
+            }
         }
         if (TRACE) {
             size_t at = (size_t)pixel * P.max_depth + bounce;
-            trace_hit[at] = hit_id;
+            trace_hit[at] = (int32_t)best_id;
             trace_mat[at] = type;
         }
 
@@ -390,7 +446,7 @@ void trace_kernel(const TraceParams P,
         if (STATS) { n_diffuse += diffuse ? 1u : 0u; n_specular += metal ? 1u : 0u; }
         if (type == 0u) color = thr * att;                            // LightSource::emit / glsl:278-280
         else if (type == 100u) color = (SEM == 0) ? thr * n : n;      // glsl:248-252
-        else if (!diffuse && !metal && type != 0xffffffffu) color = (SEM == 0) ? v3(0, 0, 0) : thr;   // glsl:253,282-284
+        else if (!diffuse && !metal && type != NONE) color = (SEM == 0) ? v3(0, 0, 0) : thr;   // glsl:253,282-284
         else if ((diffuse || metal) && !last) ended = false;
 
         // Two draws per lane: the bounce's pair, or — for a lane that starts a
@@ -545,18 +601,27 @@ __global__ void convert_kernel(uint32_t* __restrict__ accum, float* __restrict__
 
 // ------------------------------------------------------------ host launchers
 
-hipError_t launch_trace(int sem, bool stats, bool trace, dim3 grid, hipStream_t stream,
-                        const TraceParams& P, const DevShape* shapes, const DevTriangle* tris,
+template <int SEM, bool TG, int MODE>
+static hipError_t launch_one(dim3 grid, size_t lds_bytes, hipStream_t stream, const TraceParams& P, const float4* blob,
+                             uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm)
+{
+    hipLaunchKernelGGL((trace_kernel<SEM, TG, MODE>), grid, dim3(BLOCK), lds_bytes, stream, P, blob, accum, st, th, tm);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(int sem, int mode, dim3 grid, hipStream_t stream, const TraceParams& P, const void* blob,
                         uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm)
 {
-    dim3 block(BLOCK);
-#define RT_LAUNCH(S, ST, TR) \
-    hipLaunchKernelGGL((trace_kernel<S, ST, TR>), grid, block, 0, stream, P, shapes, tris, accum, st, th, tm)
-    if (trace) { if (sem == 0) RT_LAUNCH(0, false, true); else RT_LAUNCH(1, false, true); }
-    else if (stats) { if (sem == 0) RT_LAUNCH(0, true, false); else RT_LAUNCH(1, true, false); }
-    else { if (sem == 0) RT_LAUNCH(0, false, false); else RT_LAUNCH(1, false, false); }
-#undef RT_LAUNCH
-    return hipGetLastError();
+    const float4* b = static_cast<const float4*>(blob);
+    const size_t lds_bytes = (size_t)P.scene.lds_words * 16u;
+    const bool tg = P.scene.n_tris != 0 && !P.scene.tri_in_lds;
+#define RT_CASE(S, T, M) if (sem == S && tg == T && mode == M) return launch_one<S, T, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm)
+    RT_CASE(0, false, 0); RT_CASE(0, false, 1); RT_CASE(0, false, 2);
+    RT_CASE(0, true, 0);  RT_CASE(0, true, 1);  RT_CASE(0, true, 2);
+    RT_CASE(1, false, 0); RT_CASE(1, false, 1); RT_CASE(1, false, 2);
+    RT_CASE(1, true, 0);  RT_CASE(1, true, 1);  RT_CASE(1, true, 2);
+#undef RT_CASE
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_trace_fill(hipStream_t stream, int32_t* hit, uint32_t* mat, size_t n)
