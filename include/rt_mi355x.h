@@ -125,7 +125,9 @@ typedef struct rt_stats {
     uint64_t shape_tests;      /* ray-sphere + ray-box tests                     */
     uint64_t sphere_tests;
     uint64_t box_tests;
-    uint64_t triangle_tests;
+    uint64_t triangle_tests;   /* what the reference's exhaustive scan does: segments x triangles */
+    uint64_t triangle_tests_done;  /* ray-triangle tests this library executed (it culls by bounding spheres) */
+    uint64_t bound_tests_done;     /* ray-bounding-sphere tests it executed to do so */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

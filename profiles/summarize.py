@@ -14,7 +14,7 @@ from collections import defaultdict
 
 def main():
     root = sys.argv[1]
-    needle = sys.argv[2] if len(sys.argv) > 2 else "trace_kernel<0, false, false>"
+    needle = sys.argv[2] if len(sys.argv) > 2 else "trace_kernel<0, false, 0>"
     out = {"kernel": needle}
     for f in glob.glob(os.path.join(root, "trace", "**", "*_kernel_stats.csv"), recursive=True):
         for row in csv.DictReader(open(f)):

@@ -11,6 +11,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <limits>
 #include <new>
 #include <string>
 #include <vector>
@@ -113,6 +115,112 @@ static float rcp_nr(float x)
 struct Word { float f[4]; };
 static inline uint32_t& as_u32(float& f) { return reinterpret_cast<uint32_t&>(f); }
 
+
+// ---- bounding-sphere tree over the triangles ---------------------------------
+// A SimpleTriangle (shape.h:81-109) keeps one vertex, the plane and the dual basis;
+// the other two vertices follow from m1.v1 = 1, m1.v2 = 0, m2.v2 = 1, m2.v1 = 0,
+// a.v1 = a.v2 = 0:  v1 = (m2 x a) / det,  v2 = (a x m1) / det,  det = m1 . (m2 x a).
+struct TriGeom { double v[3][3]; double c[3]; bool ok; uint32_t code; };
+
+static uint32_t spread3(uint32_t v)
+{
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu; v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;  v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+static void build_tree(const std::vector<rt_triangle>& tris, const rtd::SceneLayout& L, const uint32_t* node_pad,
+                       uint32_t n_tri_pad, std::vector<Word>& blob)
+{
+    const uint32_t n = (uint32_t)tris.size();
+    std::vector<TriGeom> g(n);
+    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+    for (uint32_t i = 0; i < n; ++i) {
+        const rt_triangle& t = tris[i];
+        const double m1[3] = { t.m1[0], t.m1[1], t.m1[2] }, m2[3] = { t.m2[0], t.m2[1], t.m2[2] }, a[3] = { t.a[0], t.a[1], t.a[2] };
+        const double m2xa[3] = { m2[1] * a[2] - m2[2] * a[1], m2[2] * a[0] - m2[0] * a[2], m2[0] * a[1] - m2[1] * a[0] };
+        const double axm1[3] = { a[1] * m1[2] - a[2] * m1[1], a[2] * m1[0] - a[0] * m1[2], a[0] * m1[1] - a[1] * m1[0] };
+        const double det = m1[0] * m2xa[0] + m1[1] * m2xa[1] + m1[2] * m2xa[2];
+        TriGeom& q = g[i];
+        q.ok = true;
+        for (int k = 0; k < 3; ++k) {
+            q.v[0][k] = t.position[k];
+            q.v[1][k] = t.position[k] + m2xa[k] / det;
+            q.v[2][k] = t.position[k] + axm1[k] / det;
+            q.c[k] = (q.v[0][k] + q.v[1][k] + q.v[2][k]) / 3.0;
+            if (!std::isfinite(q.v[1][k]) || !std::isfinite(q.v[2][k]) || !std::isfinite(q.v[0][k])) q.ok = false;
+        }
+        if (q.ok) for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], q.c[k]); hi[k] = std::max(hi[k], q.c[k]); }
+    }
+    // Sort along a Morton curve through the centroids; equal codes keep upload order.
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t code = 0;
+        if (g[i].ok) {
+            uint32_t q[3];
+            for (int k = 0; k < 3; ++k) {
+                const double ext = hi[k] - lo[k];
+                q[k] = ext > 0 ? (uint32_t)std::min(1023.0, (g[i].c[k] - lo[k]) / ext * 1023.0) : 0u;
+            }
+            code = spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2);
+        }
+        g[i].code = code;
+    }
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return g[x].code < g[y].code; });
+
+    const float nan = std::nanf("");
+    // Sorted triangles, w0.w = index in the uploaded array; padding never hits (NaN plane).
+    for (uint32_t s_ = 0; s_ < n_tri_pad; ++s_) {
+        Word* w = &blob[L.tri_off + 4u * s_];
+        if (s_ < n) {
+            memcpy(w, &tris[order[s_]], sizeof(rt_triangle));
+            as_u32(w[0].f[3]) = order[s_];
+            as_u32(blob[L.inv_off + order[s_] / 4u].f[order[s_] % 4u]) = s_;
+        } else {
+            for (int k = 0; k < 4; ++k) w[k].f[0] = w[k].f[1] = w[k].f[2] = w[k].f[3] = nan;
+            as_u32(w[0].f[3]) = 0xffffffffu;
+        }
+    }
+    // Level l node i covers the sorted triangles [span*i, span*(i+1)), span = LEAF * FAN^l.
+    uint32_t span = rtd::TREE_LEAF;
+    for (uint32_t l = 0; l < rtd::TREE_LEVELS; ++l, span *= rtd::TREE_FAN) {
+        for (uint32_t i = 0; i < node_pad[l]; ++i) {
+            Word& w = blob[L.node_off[l] + i];
+            w.f[0] = w.f[1] = w.f[2] = nan; w.f[3] = 0.0f;
+            if (i >= L.node_n[l]) continue;
+            const uint64_t first = (uint64_t)span * i, last = std::min<uint64_t>(first + span, n);
+            if (first >= last) continue;
+            double blo[3] = { 1e300, 1e300, 1e300 }, bhi[3] = { -1e300, -1e300, -1e300 };
+            bool all_ok = true;
+            for (uint64_t s_ = first; s_ < last; ++s_) {
+                const TriGeom& q = g[order[s_]];
+                if (!q.ok) { all_ok = false; break; }
+                for (int v = 0; v < 3; ++v) for (int k = 0; k < 3; ++k) { blo[k] = std::min(blo[k], q.v[v][k]); bhi[k] = std::max(bhi[k], q.v[v][k]); }
+            }
+            if (!all_ok) {       // a degenerate triangle has no recoverable extent: never cull its node
+                w.f[0] = w.f[1] = w.f[2] = 0.0f; w.f[3] = std::numeric_limits<float>::infinity();
+                continue;
+            }
+            const double c[3] = { 0.5 * (blo[0] + bhi[0]), 0.5 * (blo[1] + bhi[1]), 0.5 * (blo[2] + bhi[2]) };
+            const float cf[3] = { (float)c[0], (float)c[1], (float)c[2] };
+            double r2 = 0;
+            for (uint64_t s_ = first; s_ < last; ++s_) {
+                const TriGeom& q = g[order[s_]];
+                for (int v = 0; v < 3; ++v) {
+                    double dd = 0;
+                    for (int k = 0; k < 3; ++k) { const double e = q.v[v][k] - (double)cf[k]; dd += e * e; }
+                    r2 = std::max(r2, dd);
+                }
+            }
+            const double R = 1.01 * std::sqrt(r2) + 1e-4;
+            w.f[0] = cf[0]; w.f[1] = cf[1]; w.f[2] = cf[2];
+            w.f[3] = std::nextafter((float)(R * R), std::numeric_limits<float>::infinity());
+        }
+    }
+}
+
 // Repack the uploaded arrays into the blob the kernels read (layout: rt_device.h)
 // and copy it to the device.
 static int build_blob(rt_ctx* ctx)
@@ -127,12 +235,28 @@ static int build_blob(rt_ctx* ctx)
     L.sph_off = L.rec_off + 3u * n_shapes;
     L.sid_off = L.sph_off + L.n_sph_pad;
     L.box_off = L.sid_off + L.n_sph_pad / 4u;
-    L.tri_off = L.box_off + 2u * n_box;
-    L.total_words = L.tri_off + 4u * n_tris;
-    if ((size_t)L.tri_off * 16u > rtd::LDS_MAX_BYTES)
-        return fail(ctx, RT_ERR_INVALID_ARG, "scene has %u shapes: more than fit the %u-byte LDS stage", n_shapes, rtd::LDS_MAX_BYTES);
+    // Bounding-sphere tree over the triangles (rt_device.h).
+    const uint32_t n_tri_pad = (n_tris + rtd::TREE_LEAF - 1u) / rtd::TREE_LEAF * rtd::TREE_LEAF;
+    uint32_t node_pad[rtd::TREE_LEVELS];
+    {
+        uint32_t n = n_tri_pad / rtd::TREE_LEAF;
+        for (uint32_t l = 0; l < rtd::TREE_LEVELS; ++l) {
+            L.node_n[l] = n;
+            node_pad[l] = (n + rtd::TREE_FAN - 1u) / rtd::TREE_FAN * rtd::TREE_FAN;
+            n = (n + rtd::TREE_FAN - 1u) / rtd::TREE_FAN;
+        }
+        // The top level is scanned linearly, so it is not grouped any further.
+    }
+    uint32_t off = L.box_off + 2u * n_box;
+    for (int l = (int)rtd::TREE_LEVELS - 1; l >= 0; --l) { L.node_off[l] = off; off += node_pad[l]; }
+    L.inv_off = off;
+    L.tri_off = L.inv_off + (n_tris + 3u) / 4u;
+    L.total_words = L.tri_off + 4u * n_tri_pad;
+    if ((size_t)L.inv_off * 16u > rtd::LDS_MAX_BYTES)
+        return fail(ctx, RT_ERR_INVALID_ARG, "scene (%u shapes, %u triangles) needs more than the %u-byte LDS stage for shapes and bounds",
+                    n_shapes, n_tris, rtd::LDS_MAX_BYTES);
     if ((size_t)L.total_words * 16u <= rtd::LDS_MAX_BYTES) { L.lds_words = L.total_words; L.tri_in_lds = 1; }
-    else { L.lds_words = L.tri_off; L.tri_in_lds = 0; }
+    else { L.lds_words = L.inv_off; L.tri_in_lds = 0; }
 
     std::vector<Word> blob(L.total_words ? L.total_words : 1u);
     memset(blob.data(), 0, blob.size() * sizeof(Word));
@@ -169,7 +293,7 @@ static int build_blob(rt_ctx* ctx)
         }
     }
     static_assert(sizeof(rt_triangle) == 4 * sizeof(Word), "a SimpleTriangle is four 16-byte words");
-    if (n_tris) memcpy(&blob[L.tri_off], ctx->tris.data(), (size_t)n_tris * sizeof(rt_triangle));
+    if (n_tris) build_tree(ctx->tris, L, node_pad, n_tri_pad, blob);
 
     // The kernels may still be reading the old copy.
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -401,6 +525,8 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         stats->sphere_tests = stats->segments * ctx->n_spheres;
         stats->box_tests = stats->segments * ctx->n_boxes;
         stats->triangle_tests = stats->segments * ctx->tris.size();
+        stats->triangle_tests_done = h[rtd::ST_TRI_TESTS];
+        stats->bound_tests_done = h[rtd::ST_NODE_TESTS];
     }
     return RT_OK;
 }

@@ -21,13 +21,27 @@ namespace rtd {
 //                         multiple of 4 with NaN centres (never hit)
 //   sid  [n_sph_pad / 4]  the spheres' shape indices, four per word
 //   box  [2 * n_box]      boxes in upload order: {centre.xyz, 1/side}, {shape index, 0, 0, 0}
-//   tri  [4 * n_tris]     SimpleTriangle as uploaded: {position}, {a.xyz, beta}, {m1}, {m2}
+//   node [n3p+n2p+n1p+n0p] bounding spheres over the triangles, four levels (below)
+//   inv  [n_tris / 4]     for each uploaded triangle, its place in the sorted list (uint32)
+//   tri  [4 * n_tri_pad]  SimpleTriangles sorted along a space-filling curve and padded to a
+//                         multiple of TREE_LEAF with never-hit ones: {position.xyz, index in
+//                         the uploaded array}, {a.xyz, beta}, {m1}, {m2}
+//
+// Bounding-sphere tree: level 0 node i bounds the sorted triangles [TREE_LEAF*i,
+// TREE_LEAF*(i+1)); a node i of level l+1 bounds the nodes [TREE_FAN*i, TREE_FAN*(i+1)) of
+// level l.  Every level is padded to a multiple of TREE_FAN with never-hit nodes (NaN
+// centre).  A node is {centre.xyz, R^2}, R = 1.01 * radius + 1e-4: the slack covers the
+// rounding of the triangle test itself, so that a ray the triangle test could accept is
+// never culled (see bound_hit in rt_kernels.hip).
+constexpr uint32_t TREE_LEAF = 4, TREE_FAN = 8, TREE_LEVELS = 4;
 struct SceneLayout {
     uint32_t n_shapes, n_sph_pad, n_box, n_tris;
-    uint32_t rec_off, sph_off, sid_off, box_off, tri_off;   // in 16-byte words
+    uint32_t rec_off, sph_off, sid_off, box_off, inv_off, tri_off;   // in 16-byte words
+    uint32_t node_off[TREE_LEVELS];                         // level 0 .. 3
+    uint32_t node_n[TREE_LEVELS];                           // real (unpadded) node counts
     uint32_t total_words;                                   // whole blob
     uint32_t lds_words;                                     // prefix staged in LDS
-    uint32_t tri_in_lds;                                    // 1 if the triangles are part of that prefix
+    uint32_t tri_in_lds;                                    // 1 if inv and tri are part of that prefix
 };
 
 // Everything one trace launch needs besides the blob; passed by value in the
@@ -46,7 +60,7 @@ struct TraceParams {
 };
 
 // Slots of the statistics block (uint64 each).
-enum { ST_SAMPLES = 0, ST_SEGMENTS, ST_DIFFUSE, ST_SPECULAR, ST_TERMINAL, ST_COUNT };
+enum { ST_SAMPLES = 0, ST_SEGMENTS, ST_DIFFUSE, ST_SPECULAR, ST_TERMINAL, ST_TRI_TESTS, ST_NODE_TESTS, ST_COUNT };
 
 constexpr int TILE_W = 16;     // pixels per workgroup in x (two 8-wide wave tiles)
 constexpr int TILE_H = 16;     // and in y

@@ -189,10 +189,26 @@ template <int SEM> struct Window;
 template <> struct Window<0> { static constexpr uint32_t tmin = 0x3a83126fu, far = 0x7f7fffffu; };   // 0.001f, FLT_MAX
 template <> struct Window<1> { static constexpr uint32_t tmin = 0x38d1b718u, far = 0x447a0000u; };   // next above 0.0001f, 1000.0f
 
+// The closest hit is the minimum of (distance, index) pairs in dictionary order: both
+// reference tracers scan in index order and replace the best only by a strictly smaller
+// distance (scene.h:236-252, RayTracing.glsl:212,226), and a triangle, whose index counts
+// on from the shapes', replaces a shape only when strictly closer (RayTracing.glsl:271).
+// Written as a minimum it no longer depends on the order of the tests, which frees the
+// scan order: spheres before boxes, triangles along a space-filling curve.
+struct Best { uint32_t key, id; };
+RT_DEV void take_if_closer(Best& best, uint32_t key, uint32_t id, bool also = true)
+{
+    const unsigned long long cand = ((unsigned long long)key << 32) | id;
+    const unsigned long long cur = ((unsigned long long)best.key << 32) | best.id;
+    const bool take = also && cand < cur;
+    best.key = take ? key : best.key;
+    best.id = take ? id : best.id;
+}
+
 // Sphere::hit (src/cpu_version/scene.h:115-128) = hitSphere
 // (RayTracing.glsl:118-132).  s = centre.xyz, radius^2.
 template <int SEM>
-RT_DEV void test_sphere(float4 s, uint32_t shape_id, V3 o, V3 d, uint32_t& best_key, uint32_t& best_id)
+RT_DEV void test_sphere(float4 s, uint32_t shape_id, V3 o, V3 d, Best& best)
 {
     V3 oc = v3(o.x - s.x, o.y - s.y, o.z - s.z);
     float b = dot(oc, d);
@@ -205,10 +221,7 @@ RT_DEV void test_sphere(float4 s, uint32_t shape_id, V3 o, V3 d, uint32_t& best_
     // last bit, or lies below the window.)
     if (!__any(b < 0.0f && disc >= 0.0f)) return;
     float t = -b - sqrt_rn(disc);
-    uint32_t key = __float_as_uint(t) - Window<SEM>::tmin;
-    bool take = key < best_key;
-    best_key = take ? key : best_key;
-    best_id = take ? shape_id : best_id;
+    take_if_closer(best, __float_as_uint(t) - Window<SEM>::tmin, shape_id);
 }
 
 // hitBox, RayTracing.glsl:138-156.  bx = centre.xyz, 1/side.
@@ -244,12 +257,11 @@ RT_DEV V3 box_normal(V3 c, float rs, V3 p)
     return normalize(n);
 }
 
-// hitTriangle, RayTracing.glsl:179-194, on the four words of a SimpleTriangle.
-// The early return for k < 0 (:182-184) is left to the window test, which
-// rejects every negative k.
+// hitTriangle, RayTracing.glsl:179-194, on the four words of a SimpleTriangle
+// (w0.w carries the triangle's index in the uploaded array).  The early return
+// for k < 0 (:182-184) is left to the window test, which rejects every negative k.
 template <int SEM>
-RT_DEV void test_triangle(float4 w0, float4 w1, float4 w2, float4 w3, uint32_t id, V3 o, V3 d,
-                          uint32_t& best_key, uint32_t& best_id)
+RT_DEV void test_triangle(float4 w0, float4 w1, float4 w2, float4 w3, uint32_t n_shapes, V3 o, V3 d, Best& best)
 {
     V3 a = xyz(w1);
     float k = (w1.w - dot(a, o)) * rcp_nr(dot(a, d));
@@ -257,10 +269,22 @@ RT_DEV void test_triangle(float4 w0, float4 w1, float4 w2, float4 w3, uint32_t i
     V3 q = v3(p.x - w0.x, p.y - w0.y, p.z - w0.z);
     float x = dot(q, xyz(w2));
     float y = dot(q, xyz(w3));
-    uint32_t key = __float_as_uint(k) - Window<SEM>::tmin;
-    bool take = x > 0.0f && y > 0.0f && (x + y) < 1.0f && key < best_key;
-    best_key = take ? key : best_key;
-    best_id = take ? id : best_id;
+    take_if_closer(best, __float_as_uint(k) - Window<SEM>::tmin, n_shapes + __float_as_uint(w0.w),
+                   x > 0.0f && y > 0.0f && (x + y) < 1.0f);
+}
+
+// Can the ray touch the bounding sphere nb = {centre.xyz, R^2}?  Decided from the
+// ray's closest approach w = oc - (oc.d) d, whose rounding error grows with |oc| only
+// linearly; the term 1e-6 * |oc|^2 on the right covers it (and a direction that is unit
+// only to 1e-6), R's own slack covers the triangle test's.  A NaN centre never hits.
+RT_DEV bool bound_hit(float4 nb, V3 o, V3 d)
+{
+    V3 oc = v3(o.x - nb.x, o.y - nb.y, o.z - nb.z);
+    float b = dot(oc, d);
+    V3 w = madd(-b, d, oc);
+    float oc2 = dot(oc, oc);
+    float rhs = fma_(1e-6f, oc2, nb.w);
+    return dot(w, w) <= rhs && (b < 0.0f || oc2 <= rhs);
 }
 
 // uvec4(255 * color), RayTracing.glsl:301; negative and NaN give 0, large
@@ -324,7 +348,7 @@ void trace_kernel(const TraceParams P,
         acc0 = v.x; acc1 = v.y; acc2 = v.z;
     }
 
-    uint32_t n_samples = 0, n_segments = 0, n_diffuse = 0, n_specular = 0, n_terminal = 0;
+    uint32_t n_samples = 0, n_segments = 0, n_diffuse = 0, n_specular = 0, n_terminal = 0, n_tri = 0, n_node = 0;
 
     uint32_t sample = TRACE ? P.trace_sample : P.first_sample;
     const uint32_t sample_end = TRACE ? P.trace_sample + 1u : P.first_sample + P.spp;
@@ -369,7 +393,14 @@ void trace_kernel(const TraceParams P,
     const float4* const box = lds + L.box_off;
     const float4* const rec = lds + L.rec_off;
     const float4* const tri = TRI_GLOBAL ? blob + L.tri_off : lds + L.tri_off;
-    const uint32_t n_chunks = L.n_sph_pad >> 2, n_box = L.n_box, n_tris = L.n_tris, n_shapes = L.n_shapes;
+    const uint32_t* const slot_of = reinterpret_cast<const uint32_t*>(TRI_GLOBAL ? blob + L.inv_off : lds + L.inv_off);
+    const float4* const node0 = lds + L.node_off[0];
+    const float4* const node1 = lds + L.node_off[1];
+    const float4* const node2 = lds + L.node_off[2];
+    const float4* const node3 = lds + L.node_off[3];
+    const uint32_t n_chunks = L.n_sph_pad >> 2, n_box = L.n_box, n_shapes = L.n_shapes;
+    // The bounds assume a unit direction; the as-written fuzzy metal leaves it unnormalised.
+    const bool cull = (P.flags & 1u) == 0u;
     constexpr uint32_t NONE = 0xffffffffu;
 
     while (alive) {
@@ -379,32 +410,53 @@ void trace_kernel(const TraceParams P,
         //      and every replacement needs a strictly smaller distance, so a
         //      triangle wins only when strictly closer than the closest shape
         //      (glsl:271) and the first of equal distances stays.
-        uint32_t best_key = Window<SEM>::far - Window<SEM>::tmin;
-        uint32_t best_id = NONE;
+        Best best = { Window<SEM>::far - Window<SEM>::tmin, NONE };
         for (uint32_t c = 0; c < n_chunks; ++c) {
             const float4 s0 = sph[4u * c], s1 = sph[4u * c + 1u], s2 = sph[4u * c + 2u], s3 = sph[4u * c + 3u];
             const float4 ids = sid[c];
-            test_sphere<SEM>(s0, __float_as_uint(ids.x), o, d, best_key, best_id);
-            test_sphere<SEM>(s1, __float_as_uint(ids.y), o, d, best_key, best_id);
-            test_sphere<SEM>(s2, __float_as_uint(ids.z), o, d, best_key, best_id);
-            test_sphere<SEM>(s3, __float_as_uint(ids.w), o, d, best_key, best_id);
+            test_sphere<SEM>(s0, __float_as_uint(ids.x), o, d, best);
+            test_sphere<SEM>(s1, __float_as_uint(ids.y), o, d, best);
+            test_sphere<SEM>(s2, __float_as_uint(ids.z), o, d, best);
+            test_sphere<SEM>(s3, __float_as_uint(ids.w), o, d, best);
         }
         for (uint32_t i = 0; i < n_box; ++i) {
             const float4 bx = box[2u * i];
             const uint32_t bid = __float_as_uint(box[2u * i + 1u].x);
-            float t = hit_box(bx, o, d);
-            uint32_t k = __float_as_uint(t) - Window<SEM>::tmin;
-            // Spheres were scanned before boxes whatever their place in the uploaded
-            // array: at equal distance the lower shape index wins, as it would have
-            // in the reference's single scan.
-            bool take = k < best_key || (k == best_key && best_id != NONE && bid < best_id);
-            best_key = take ? k : best_key;
-            best_id = take ? bid : best_id;
+            take_if_closer(best, __float_as_uint(hit_box(bx, o, d)) - Window<SEM>::tmin, bid);
         }
-        for (uint32_t i = 0; i < n_tris; ++i) {
-            const float4 w0 = tri[4u * i], w1 = tri[4u * i + 1u], w2 = tri[4u * i + 2u], w3 = tri[4u * i + 3u];
-            test_triangle<SEM>(w0, w1, w2, w3, n_shapes + i, o, d, best_key, best_id);
+        // Triangles: walk the four-level bounding-sphere tree with the whole wave; a
+        // subtree is entered when the ray of any live lane can touch its sphere.
+        for (uint32_t i3 = 0; i3 < L.node_n[3]; ++i3) {
+            if (STATS) ++n_node;
+            if (cull && !__any(bound_hit(node3[i3], o, d))) continue;
+            const uint32_t e2 = min(TREE_FAN * i3 + TREE_FAN, L.node_n[2]);
+            for (uint32_t i2 = TREE_FAN * i3; i2 < e2; ++i2) {
+                if (STATS) ++n_node;
+                if (cull && !__any(bound_hit(node2[i2], o, d))) continue;
+                const uint32_t e1 = min(TREE_FAN * i2 + TREE_FAN, L.node_n[1]);
+                for (uint32_t i1 = TREE_FAN * i2; i1 < e1; ++i1) {
+                    if (STATS) ++n_node;
+                    if (cull && !__any(bound_hit(node1[i1], o, d))) continue;
+                    const uint32_t e0 = min(TREE_FAN * i1 + TREE_FAN, L.node_n[0]);
+                    for (uint32_t i0 = TREE_FAN * i1; i0 < e0; ++i0) {
+                        if (STATS) ++n_node;
+                        if (cull && !__any(bound_hit(node0[i0], o, d))) continue;
+#pragma unroll
+                        for (uint32_t k = 0; k < TREE_LEAF; ++k) {
+                            const uint32_t ti = TREE_LEAF * i0 + k;
+                            float4 w0 = tri[4u * ti], w1 = tri[4u * ti + 1u], w2 = tri[4u * ti + 2u], w3 = tri[4u * ti + 3u];
+                            // Only xyz of two of the words is used, which would let the compiler
+                            // fetch 12 bytes each — and a 12-byte LDS read costs twice the LDS
+                            // cycles of a 16-byte one.
+                            if (!TRI_GLOBAL) asm volatile("" : "+v"(w2.w), "+v"(w3.w));
+                            test_triangle<SEM>(w0, w1, w2, w3, n_shapes, o, d, best);
+                        }
+                        if (STATS) n_tri += TREE_LEAF;
+                    }
+                }
+            }
         }
+        const uint32_t best_key = best.key, best_id = best.id;
         if (STATS) ++n_segments;
 
         // ---- the surface
@@ -415,7 +467,7 @@ void trace_kernel(const TraceParams P,
         const V3 p = madd(t_hit, d, o);                               // Ray::at / glsl:239
         if (best_id != NONE) {
             if (best_id >= n_shapes) {
-                V3 a = xyz(tri[4u * (best_id - n_shapes) + 1u]);
+                V3 a = xyz(tri[4u * slot_of[best_id - n_shapes] + 1u]);
                 n = a * sign_(-dot(d, a));                            // glsl:165-167,272
                 att = v3(P.tri_albedo[0], P.tri_albedo[1], P.tri_albedo[2]);
                 type = 1u;
@@ -515,7 +567,7 @@ void trace_kernel(const TraceParams P,
             }
         }
         const V3 nd = normalize(v);
-        d = raw_dir ? v : nd;
+        d = v3(raw_dir ? v.x : nd.x, raw_dir ? v.y : nd.y, raw_dir ? v.z : nd.z);   // per component: a struct select goes through scratch memory
     }
 
     if (!TRACE && valid) {
@@ -525,7 +577,7 @@ void trace_kernel(const TraceParams P,
 
     if (STATS) {
         // Sum over the wave with cross-lane shuffles, one atomic per wave and counter.
-        uint32_t c[ST_COUNT] = { n_samples, n_segments, n_diffuse, n_specular, n_terminal };
+        uint32_t c[ST_COUNT] = { n_samples, n_segments, n_diffuse, n_specular, n_terminal, n_tri, n_node };
 #pragma unroll
         for (int k = 0; k < ST_COUNT; ++k) {
             unsigned long long v = c[k];
