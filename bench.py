@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--shard", default="samples", choices=["samples", "rows"])
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel per rank")
+    ap.add_argument("--width", type=int, default=0, help="override the frame width (experiments)")
+    ap.add_argument("--height", type=int, default=0, help="override the frame height (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -91,7 +93,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    cfg = rta.scenes.CONFIGS[args.config]()
+    cfg = rta.scenes.CONFIGS[args.config](**({"width": args.width, "height": args.height} if args.width and args.height else {}))
     if args.spp:
         cfg.spp = args.spp
     shard = parallel.plan(args.shard, rank, world, cfg.spp)

@@ -128,6 +128,7 @@ typedef struct rt_stats {
     uint64_t triangle_tests;   /* what the reference's exhaustive scan does: segments x triangles */
     uint64_t triangle_tests_done;  /* ray-triangle tests this library executed (it culls by bounding spheres) */
     uint64_t bound_tests_done;     /* ray-bounding-sphere tests it executed to do so */
+    uint64_t wave_iterations;      /* loop iterations summed over waves: segments / (64 * this) = lane use */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;
@@ -198,6 +199,15 @@ int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp,
 int rt_render_stats(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp,
                     uint32_t max_depth, uint64_t seed, uint32_t first_sample,
                     uint32_t grid_n, rt_stats* out);
+
+/* Diagnostic: rt_render_stats that also records, per wave of the launch (four per
+ * 16x16-pixel tile, in launch order), {start, end} of its loop in 100 MHz ticks, the
+ * hardware id register and the loop's length.  timeline_host: 4 int32 per wave,
+ * timeline_waves = capacity in waves.  No counterpart in the reference. */
+int rt_render_timeline(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp,
+                       uint32_t max_depth, uint64_t seed, uint32_t first_sample,
+                       uint32_t grid_n, rt_stats* out, int32_t* timeline_host,
+                       uint32_t timeline_waves);
 
 /* Number of samples per pixel added to the accumulator since the last reset. */
 int rt_accum_samples(const rt_ctx* ctx, uint32_t* out);

@@ -37,7 +37,7 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "segments", "diffuse", "specular", "terminal",
                                           "shape_tests", "sphere_tests", "box_tests", "triangle_tests",
-                                          "triangle_tests_done", "bound_tests_done")]
+                                          "triangle_tests_done", "bound_tests_done", "wave_iterations")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -59,6 +59,7 @@ SIGNATURES = {
     "rt_bind_accum": (_int, [_vp, _vp, _u32, _u32]),
     "rt_render": (_int, [_vp, _u32, _u32, _u32, _u32, _u64, _u32, _u32]),
     "rt_render_stats": (_int, [_vp, _u32, _u32, _u32, _u32, _u64, _u32, _u32, C.POINTER(Stats)]),
+    "rt_render_timeline": (_int, [_vp, _u32, _u32, _u32, _u32, _u64, _u32, _u32, C.POINTER(Stats), _vp, _u32]),
     "rt_accum_samples": (_int, [_vp, C.POINTER(_u32)]),
     "rt_set_accum_samples": (_int, [_vp, _u32]),
     "rt_reset_accum": (_int, [_vp]),

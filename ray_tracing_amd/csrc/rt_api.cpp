@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <algorithm>
 #include <limits>
 #include <new>
@@ -21,8 +22,10 @@
 #include "rt_device.h"
 
 namespace rtd {
-hipError_t launch_trace(int sem, int mode, dim3 grid, hipStream_t stream, const TraceParams& P, const void* blob,
-                        uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm);
+hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams& P, const void* blob,
+                        uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm,
+                        const uint32_t* tile_order, uint32_t* tile_cost);
+hipError_t launch_tile_order(hipStream_t stream, uint32_t* cost, uint32_t* order, uint32_t n);
 hipError_t launch_trace_fill(hipStream_t stream, int32_t* hit, uint32_t* mat, size_t n);
 hipError_t launch_resolve(int sem, hipStream_t stream, const uint32_t* accum, float* out, uint32_t w, uint32_t h,
                           uint32_t samples, int gamma_sqrt, int flip_rows);
@@ -63,6 +66,14 @@ struct rt_ctx {
     uint32_t shard_index = 0, shard_count = 1, band_rows = 16;
 
     unsigned long long* d_stats = nullptr;
+
+    // Launch order of the tiles, learnt from the previous frame of the same tiling.
+    uint32_t* d_tile_cost = nullptr;     // per tile: iterations of its longest wave
+    uint32_t* d_tile_order = nullptr;    // tiles, most expensive first
+    uint32_t tile_cap = 0;               // entries allocated
+    uint32_t order_tiles_x = 0, order_tiles_y = 0;   // tiling d_tile_order is valid for (0 = none yet)
+
+    int compute_units = 0;
 };
 
 static thread_local std::string g_create_error;
@@ -341,6 +352,10 @@ int rt_create(rt_ctx** out, const rt_config* cfg)
     ctx->device = c.device;
     e = hipMalloc(&ctx->d_stats, sizeof(unsigned long long) * rtd::ST_COUNT);
     if (e != hipSuccess) { delete ctx; return fail(nullptr, RT_ERR_OUT_OF_MEMORY, "hipMalloc(stats): %s", hipGetErrorString(e)); }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, c.device);
+    if (e != hipSuccess) { (void)hipFree(ctx->d_stats); delete ctx; return fail(nullptr, RT_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); }
+    ctx->compute_units = prop.multiProcessorCount;
     *out = ctx;
     return RT_OK;
 }
@@ -354,6 +369,8 @@ void rt_destroy(rt_ctx* ctx)
     (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_image);
     (void)hipFree(ctx->d_stats);
+    (void)hipFree(ctx->d_tile_cost);
+    (void)hipFree(ctx->d_tile_order);
     delete ctx;
 }
 
@@ -486,16 +503,39 @@ static int fill_params(rt_ctx* ctx, rtd::TraceParams& P, uint32_t width, uint32_
     if (ctx->shard_count <= 1) { P.shard_index = 0; P.shard_count = 1; P.band_rows = height; }
     else { P.shard_index = ctx->shard_index; P.shard_count = ctx->shard_count; P.band_rows = ctx->band_rows; }
     P.owned_rows = owned_rows(ctx, height);
+    P.tiles_x = (P.width + rtd::TILE_W - 1) / rtd::TILE_W;
+    P.tiles_y = (P.owned_rows + rtd::TILE_H - 1) / rtd::TILE_H;
     return RT_OK;
 }
 
-static dim3 trace_grid(const rtd::TraceParams& P)
+// Makes room for the per-tile cost and order arrays of a tiles_x x tiles_y launch.
+static int ensure_tiles(rt_ctx* ctx, const rtd::TraceParams& P)
 {
-    return dim3((P.width + rtd::TILE_W - 1) / rtd::TILE_W, (P.owned_rows + rtd::TILE_H - 1) / rtd::TILE_H);
+    const uint32_t n = P.tiles_x * P.tiles_y;
+    if (n > ctx->tile_cap) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        RT_HIP(ctx, hipFree(ctx->d_tile_cost)); ctx->d_tile_cost = nullptr;
+        RT_HIP(ctx, hipFree(ctx->d_tile_order)); ctx->d_tile_order = nullptr;
+        ctx->tile_cap = 0; ctx->order_tiles_x = ctx->order_tiles_y = 0;
+        RT_HIP(ctx, hipMalloc(&ctx->d_tile_cost, sizeof(uint32_t) * n));
+        RT_HIP(ctx, hipMalloc(&ctx->d_tile_order, sizeof(uint32_t) * n));
+        ctx->tile_cap = n;
+    }
+    return RT_OK;
+}
+
+// One launch of the trace kernel: one workgroup per 16x16-pixel tile.
+static int launch_tiles(rt_ctx* ctx, int mode, rtd::TraceParams& P, uint32_t* accum, int32_t* th, uint32_t* tm,
+                        const uint32_t* order, uint32_t* cost)
+{
+    RT_HIP(ctx, rtd::launch_trace((int)ctx->cfg.semantics, mode, ctx->stream, P, ctx->d_blob, accum, ctx->d_stats, th, tm,
+                                  order, cost));
+    return RT_OK;
 }
 
 static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth,
-                       uint64_t seed, uint32_t first_sample, uint32_t grid_n, rt_stats* stats)
+                       uint64_t seed, uint32_t first_sample, uint32_t grid_n, rt_stats* stats,
+                       int32_t* timeline_host = nullptr, uint32_t timeline_waves = 0)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -507,8 +547,31 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
     if (stats) RT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * rtd::ST_COUNT, ctx->stream));
     if (ctx->blob_dirty) { rc = build_blob(ctx); if (rc) return rc; }
     if (spp > 0 && P.owned_rows > 0) {
-        RT_HIP(ctx, rtd::launch_trace((int)ctx->cfg.semantics, stats ? 1 : 0, trace_grid(P), ctx->stream, P,
-                                      ctx->d_blob, accum_ptr(ctx), ctx->d_stats, nullptr, nullptr));
+        rc = ensure_tiles(ctx, P);
+        if (rc) return rc;
+        const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+        // The order learnt from the last frame holds while the tiling stays the same; a new
+        // tiling starts from the built-in order and clean costs.
+        const bool have_order = ctx->order_tiles_x == P.tiles_x && ctx->order_tiles_y == P.tiles_y && !getenv("RT_NO_TILE_ORDER");
+        if (!have_order) RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, sizeof(uint32_t) * n_tiles, ctx->stream));
+        int32_t* d_timeline = nullptr;
+        if (timeline_host) {
+            if (timeline_waves < 4u * n_tiles) return fail(ctx, RT_ERR_INVALID_ARG, "timeline buffer holds %u waves, the launch has %u", timeline_waves, 4u * n_tiles);
+            RT_HIP(ctx, hipMalloc(&d_timeline, sizeof(int32_t) * 16u * n_tiles));
+            RT_HIP(ctx, hipMemsetAsync(d_timeline, 0, sizeof(int32_t) * 16u * n_tiles, ctx->stream));
+        }
+        rc = launch_tiles(ctx, stats ? 1 : 0, P, accum_ptr(ctx), d_timeline, nullptr,
+                                  have_order ? ctx->d_tile_order : nullptr, ctx->d_tile_cost);
+        if (rc) { if (d_timeline) (void)hipFree(d_timeline); return rc; }
+        hipError_t le = hipSuccess;
+        if (le == hipSuccess && d_timeline) {
+            le = hipMemcpyAsync(timeline_host, d_timeline, sizeof(int32_t) * 16u * n_tiles, hipMemcpyDeviceToHost, ctx->stream);
+            if (le == hipSuccess) le = hipStreamSynchronize(ctx->stream);
+        }
+        if (d_timeline) (void)hipFree(d_timeline);
+        RT_HIP(ctx, le);
+        RT_HIP(ctx, rtd::launch_tile_order(ctx->stream, ctx->d_tile_cost, ctx->d_tile_order, n_tiles));
+        ctx->order_tiles_x = P.tiles_x; ctx->order_tiles_y = P.tiles_y;
     }
     ctx->accum_samples += spp;
     if (stats) {
@@ -527,6 +590,7 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         stats->triangle_tests = stats->segments * ctx->tris.size();
         stats->triangle_tests_done = h[rtd::ST_TRI_TESTS];
         stats->bound_tests_done = h[rtd::ST_NODE_TESTS];
+        stats->wave_iterations = h[rtd::ST_WAVE_ITERS];
     }
     return RT_OK;
 }
@@ -542,6 +606,14 @@ int rt_render_stats(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, 
 {
     if (ctx && !out) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render_stats: out is NULL");
     return render_impl(ctx, width, height, spp, max_depth, seed, first_sample, grid_n, out);
+}
+
+int rt_render_timeline(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth,
+                       uint64_t seed, uint32_t first_sample, uint32_t grid_n, rt_stats* out,
+                       int32_t* timeline_host, uint32_t timeline_waves)
+{
+    if (ctx && (!out || !timeline_host)) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render_timeline: output is NULL");
+    return render_impl(ctx, width, height, spp, max_depth, seed, first_sample, grid_n, out, timeline_host, timeline_waves);
 }
 
 int rt_accum_samples(const rt_ctx* ctx, uint32_t* out)
@@ -651,9 +723,10 @@ int rt_trace_debug(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t max_de
     if (e != hipSuccess) { (void)hipFree(d_hit); return fail(ctx, RT_ERR_OUT_OF_MEMORY, "hipMalloc(trace): %s", hipGetErrorString(e)); }
     e = rtd::launch_trace_fill(ctx->stream, d_hit, d_mat, n);
     // accum is not touched by a TRACE launch; pass any valid pointer.
-    if (e == hipSuccess)
-        e = rtd::launch_trace((int)ctx->cfg.semantics, 2, trace_grid(P), ctx->stream, P, ctx->d_blob,
-                              reinterpret_cast<uint32_t*>(d_hit), ctx->d_stats, d_hit, d_mat);
+    if (e == hipSuccess) {
+        rc = launch_tiles(ctx, 2, P, reinterpret_cast<uint32_t*>(d_hit), d_hit, d_mat, nullptr, nullptr);
+        if (rc) { (void)hipFree(d_hit); (void)hipFree(d_mat); return rc; }
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(hit_index_host, d_hit, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(material_id_host, d_mat, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

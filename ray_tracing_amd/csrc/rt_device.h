@@ -56,11 +56,12 @@ struct TraceParams {
     uint32_t shard_index, shard_count, band_rows;
     uint32_t owned_rows;       // rows of this shard
     uint32_t trace_sample;     // TRACE launches: the one sample to follow
+    uint32_t tiles_x, tiles_y; // 16x16-pixel tiles covering width x owned_rows
     SceneLayout scene;
 };
 
 // Slots of the statistics block (uint64 each).
-enum { ST_SAMPLES = 0, ST_SEGMENTS, ST_DIFFUSE, ST_SPECULAR, ST_TERMINAL, ST_TRI_TESTS, ST_NODE_TESTS, ST_COUNT };
+enum { ST_SAMPLES = 0, ST_SEGMENTS, ST_DIFFUSE, ST_SPECULAR, ST_TERMINAL, ST_TRI_TESTS, ST_NODE_TESTS, ST_WAVE_ITERS, ST_COUNT };
 
 constexpr int TILE_W = 16;     // pixels per workgroup in x (two 8-wide wave tiles)
 constexpr int TILE_H = 16;     // and in y

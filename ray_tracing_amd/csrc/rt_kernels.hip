@@ -28,6 +28,7 @@
 // bit by scalar IEEE-754 code on a CPU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "rt_device.h"
 
 namespace rtd {
@@ -314,7 +315,9 @@ void trace_kernel(const TraceParams P,
                   uint32_t* __restrict__ accum,
                   unsigned long long* __restrict__ stats,
                   int32_t* __restrict__ trace_hit,
-                  uint32_t* __restrict__ trace_mat)
+                  uint32_t* __restrict__ trace_mat,
+                  const uint32_t* __restrict__ tile_order,
+                  uint32_t* __restrict__ tile_cost)
 {
     constexpr bool STATS = MODE == 1, TRACE = MODE == 2;
     extern __shared__ float4 lds[];
@@ -322,11 +325,24 @@ void trace_kernel(const TraceParams P,
     for (uint32_t i = tid; i < P.scene.lds_words; i += BLOCK) lds[i] = blob[i];
     __syncthreads();
 
-    const uint32_t wave = tid >> 6, lane = tid & 63u;
-    const uint32_t gx = blockIdx.x * TILE_W + (wave & 1u) * 8u + (lane & 7u);
-    // Workgroups are handed out in blockIdx order; the bottom rows of a frame
-    // (ground, objects: long paths) go first, the top rows (sky) fill the tail.
-    const uint32_t row = (gridDim.y - 1u - blockIdx.y) * TILE_H + (wave >> 1) * 8u + (lane >> 3);   // ordinal among owned rows
+    const uint32_t lane = tid & 63u;
+    uint32_t n_samples = 0, n_segments = 0, n_diffuse = 0, n_specular = 0, n_terminal = 0, n_tri = 0, n_node = 0, n_iterations = 0;
+
+    // One 8x8-pixel tile per wave, four waves (a 16x16 tile) per workgroup; workgroups start in
+    // blockIdx order.  tile_order lists the 16x16 tiles that cost more than twice the mean in the
+    // previous frame of this view first, so that the launch does not end waiting for them; without
+    // it the bottom rows of the frame (ground, objects) go first and the top rows (sky) last.  Any
+    // order gives the same image.  (Handing tiles out dynamically through a device-wide counter
+    // to a resident set of waves was tried: it evens out XCDs that run at different speeds in the
+    // first launches of a process, but costs 10 registers and was 5 % slower in steady state.)
+    const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    const uint32_t q = blockIdx.x * 4u + (tid >> 6);
+    {
+    const uint32_t slot = q >> 2, sub = q & 3u;
+    const uint32_t tile = tile_order ? tile_order[slot] : (n_tiles - 1u - slot);
+    const uint32_t tile_y = tile / P.tiles_x, tile_x = tile - tile_y * P.tiles_x;
+    const uint32_t gx = tile_x * TILE_W + (sub & 1u) * 8u + (lane & 7u);
+    const uint32_t row = tile_y * TILE_H + (sub >> 1) * 8u + (lane >> 3);   // ordinal among owned rows
     const uint32_t band = row / P.band_rows;
     const uint32_t gy = (band * P.shard_count + P.shard_index) * P.band_rows + (row - band * P.band_rows);
     const bool valid = gx < P.width && row < P.owned_rows && gy < P.height;
@@ -347,8 +363,6 @@ void trace_kernel(const TraceParams P,
         uint4 v = *reinterpret_cast<const uint4*>(acc_ptr);
         acc0 = v.x; acc1 = v.y; acc2 = v.z;
     }
-
-    uint32_t n_samples = 0, n_segments = 0, n_diffuse = 0, n_specular = 0, n_terminal = 0, n_tri = 0, n_node = 0;
 
     uint32_t sample = TRACE ? P.trace_sample : P.first_sample;
     const uint32_t sample_end = TRACE ? P.trace_sample + 1u : P.first_sample + P.spp;
@@ -403,7 +417,11 @@ void trace_kernel(const TraceParams P,
     const bool cull = (P.flags & 1u) == 0u;
     constexpr uint32_t NONE = 0xffffffffu;
 
+    uint32_t iterations = 0;           // wave-uniform
+    const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long c_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     while (alive) {
+        ++iterations;
         // ---- closest hit: Scene::hit (scene.h:232-255) /
         //      getClosestShapeIndex + getClosestTriangleIndex (glsl:206-231).
         //      One running (key, id) serves shapes and triangles: shapes come first
@@ -457,7 +475,7 @@ void trace_kernel(const TraceParams P,
             }
         }
         const uint32_t best_key = best.key, best_id = best.id;
-        if (STATS) ++n_segments;
+        if (STATS) { ++n_segments; }
 
         // ---- the surface
         uint32_t type = NONE;                  // nothing hit
@@ -574,10 +592,23 @@ void trace_kernel(const TraceParams P,
         uint4 v; v.x = acc0; v.y = acc1; v.z = acc2; v.w = 0u;
         *reinterpret_cast<uint4*>(acc_ptr) = v;
     }
+    // What this tile cost, for the next frame's launch order: the longest of its four waves' loops.
+    if (!TRACE && tile_cost && lane == 0u) atomicMax(&tile_cost[tile], iterations);
+    if (STATS && trace_hit && lane == 0u) {
+        // Diagnostic timeline: start and end of this wave tile's loop (100 MHz ticks), where it ran, how long its loop was.
+        int32_t* rec4 = trace_hit + 4u * q;
+        rec4[0] = (int32_t)(uint32_t)t_start;
+        rec4[1] = (int32_t)(uint32_t)__builtin_amdgcn_s_memrealtime();
+        rec4[2] = (int32_t)((((uint32_t)(__builtin_amdgcn_s_memtime() - c_start)) >> 4) |                       // shader clocks / 16
+                            (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 28));                      // XCC_ID
+        rec4[3] = (int32_t)iterations;
+    }
+    n_iterations += iterations;
+    }
 
     if (STATS) {
         // Sum over the wave with cross-lane shuffles, one atomic per wave and counter.
-        uint32_t c[ST_COUNT] = { n_samples, n_segments, n_diffuse, n_specular, n_terminal, n_tri, n_node };
+        uint32_t c[ST_COUNT] = { n_samples, n_segments, n_diffuse, n_specular, n_terminal, n_tri, n_node, (lane == 0u) ? n_iterations : 0u };
 #pragma unroll
         for (int k = 0; k < ST_COUNT; ++k) {
             unsigned long long v = c[k];
@@ -585,6 +616,92 @@ void trace_kernel(const TraceParams P,
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
             if (lane == 0 && v) atomicAdd(&stats[k], v);
         }
+    }
+}
+
+// Turns the per-tile costs of the frame just traced into the launch order of the next
+// one, and clears the costs.  Tiles that cost more than twice the mean (a mesh in one
+// corner of the frame) go first, so that the launch does not end waiting for them; all
+// other tiles keep the built-in order (bottom rows first), which interleaves long and
+// short tiles on every CU — measured faster than a full longest-first sort, whose tail
+// of short tiles is all start-up latency.  One workgroup.
+__global__ __launch_bounds__(1024)
+void tile_order_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n)
+{
+    __shared__ uint32_t scan[1024];
+    __shared__ unsigned long long total;
+    __shared__ uint32_t n_front;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0u) { total = 0ull; n_front = 0u; }
+    __syncthreads();
+    unsigned long long sum = 0ull;
+    for (uint32_t i = tid; i < n; i += 1024u) sum += cost[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+    if ((tid & 63u) == 0u) atomicAdd(&total, sum);
+    __syncthreads();
+    const uint32_t limit = (uint32_t)min(0xffffffffull, 2ull * total / n);      // twice the mean
+    // Position j of the built-in order is tile n-1-j; thread t owns positions [t*chunk, (t+1)*chunk).
+    const uint32_t chunk = (n + 1023u) / 1024u;
+    const uint32_t j0 = min(n, tid * chunk), j1 = min(n, j0 + chunk);
+    uint32_t keep = 0u;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const uint32_t tile = n - 1u - j;
+        if (cost[tile] > limit) order[atomicAdd(&n_front, 1u)] = tile;
+        else ++keep;
+    }
+    scan[tid] = keep;
+    __syncthreads();
+    for (uint32_t off = 1u; off < 1024u; off <<= 1) {
+        const uint32_t v = tid >= off ? scan[tid - off] : 0u;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    uint32_t at = n_front + scan[tid] - keep;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const uint32_t tile = n - 1u - j;
+        if (!(cost[tile] > limit)) order[at++] = tile;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 1024u) cost[i] = 0u;
+}
+
+// Full longest-first order (counting sort over 256 cost classes).  Kept for experiments.
+__global__ __launch_bounds__(1024)
+void tile_order_lpt_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t scan[256];
+    __shared__ uint32_t max_cost;
+    const uint32_t tid = threadIdx.x;
+    if (tid < 256u) hist[tid] = 0u;
+    if (tid == 0u) max_cost = 1u;
+    __syncthreads();
+    uint32_t m = 0u;
+    for (uint32_t i = tid; i < n; i += 1024u) m = max(m, cost[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, off, 64));
+    if ((tid & 63u) == 0u) atomicMax(&max_cost, m);
+    __syncthreads();
+    const float scale = 255.0f / (float)max_cost;
+    auto cls = [&](uint32_t c) { return 255u - min(255u, (uint32_t)((float)c * scale)); };
+    for (uint32_t i = tid; i < n; i += 1024u) atomicAdd(&hist[cls(cost[i])], 1u);
+    __syncthreads();
+    if (tid < 256u) scan[tid] = hist[tid];
+    __syncthreads();
+    for (uint32_t off = 1u; off < 256u; off <<= 1) {
+        uint32_t v = 0u;
+        if (tid < 256u && tid >= off) v = scan[tid - off];
+        __syncthreads();
+        if (tid < 256u) scan[tid] += v;
+        __syncthreads();
+    }
+    if (tid < 256u) hist[tid] = scan[tid] - hist[tid];
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 1024u) {
+        order[atomicAdd(&hist[cls(cost[i])], 1u)] = i;
+        cost[i] = 0u;
     }
 }
 
@@ -655,19 +772,31 @@ __global__ void convert_kernel(uint32_t* __restrict__ accum, float* __restrict__
 
 template <int SEM, bool TG, int MODE>
 static hipError_t launch_one(dim3 grid, size_t lds_bytes, hipStream_t stream, const TraceParams& P, const float4* blob,
-                             uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm)
+                             uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm,
+                             const uint32_t* tile_order, uint32_t* tile_cost)
 {
-    hipLaunchKernelGGL((trace_kernel<SEM, TG, MODE>), grid, dim3(BLOCK), lds_bytes, stream, P, blob, accum, st, th, tm);
+    hipLaunchKernelGGL((trace_kernel<SEM, TG, MODE>), grid, dim3(BLOCK), lds_bytes, stream, P, blob, accum, st, th, tm,
+                       tile_order, tile_cost);
     return hipGetLastError();
 }
 
-hipError_t launch_trace(int sem, int mode, dim3 grid, hipStream_t stream, const TraceParams& P, const void* blob,
-                        uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm)
+hipError_t launch_tile_order(hipStream_t stream, uint32_t* cost, uint32_t* order, uint32_t n)
 {
+    static const bool lpt = getenv("RT_TILE_LPT") != nullptr;
+    if (lpt) hipLaunchKernelGGL(tile_order_lpt_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n);
+    else hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams& P, const void* blob,
+                        uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm,
+                        const uint32_t* tile_order, uint32_t* tile_cost)
+{
+    const dim3 grid(P.tiles_x * P.tiles_y);
     const float4* b = static_cast<const float4*>(blob);
     const size_t lds_bytes = (size_t)P.scene.lds_words * 16u;
     const bool tg = P.scene.n_tris != 0 && !P.scene.tri_in_lds;
-#define RT_CASE(S, T, M) if (sem == S && tg == T && mode == M) return launch_one<S, T, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm)
+#define RT_CASE(S, T, M) if (sem == S && tg == T && mode == M) return launch_one<S, T, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm, tile_order, tile_cost)
     RT_CASE(0, false, 0); RT_CASE(0, false, 1); RT_CASE(0, false, 2);
     RT_CASE(0, true, 0);  RT_CASE(0, true, 1);  RT_CASE(0, true, 2);
     RT_CASE(1, false, 0); RT_CASE(1, false, 1); RT_CASE(1, false, 2);
