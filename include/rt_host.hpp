@@ -67,6 +67,11 @@ public:
         rt_make_box(this, translation.data(), sides.data(), &material);
     }
 };
+class Cube : public Shape {                  // the CPU tracer's Cube, src/cpu_version/scene.h:142-217
+public:
+    Cube(const Vector3f& center, const Material& material) { rt_make_cube(this, center.data(), &material); }
+    void rotate(float angle) { rt_cube_rotate(this, angle); }   // scene.h:206-208
+};
 static_assert(sizeof(Shape) == 144, "Shape must keep the layout of shape.h:44-54");
 
 class SimpleTriangle : public rt_triangle {  // shape.h:81-109

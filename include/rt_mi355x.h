@@ -74,7 +74,12 @@ typedef struct rt_triangle {
 
 enum rt_material_type { RT_MAT_LIGHT = 0, RT_MAT_LAMBERTIAN = 1, RT_MAT_METAL = 2,
                         RT_MAT_DIELECTRIC = 3, RT_MAT_DEBUG = 100 };
-enum rt_shape_type    { RT_SHAPE_CIRCLE = 0, RT_SHAPE_BOX = 1 };
+/* 0 and 1 are the shader's shapes (shape.h:56-70).  RT_SHAPE_CUBE is the CPU tracer's Cube
+ * (src/cpu_version/scene.h:142-217): a unit cube, its rotation matrix in the upper-left 3x3 of
+ * `transformation`, its centre in column 3; hit only under RT_SEM_CPU (the shader's hit() returns
+ * -1 for a type it does not know, RayTracing.glsl:176).  The shader's own type 2 (Triangle,
+ * shape.h:72-79) is never hit there either. */
+enum rt_shape_type    { RT_SHAPE_CIRCLE = 0, RT_SHAPE_BOX = 1, RT_SHAPE_CUBE = 3 };
 
 /* Which of the reference's two tracers the context reproduces. */
 enum rt_semantics {
@@ -276,6 +281,10 @@ void rt_make_circle(rt_shape* out, const float translation[3], float radius,
                     const rt_material* material);
 void rt_make_box(rt_shape* out, const float translation[3], const float sides[3],
                  const rt_material* material);
+/* Cube::Cube and Cube::rotate of the CPU tracer (src/cpu_version/scene.h:144-148, :206-208):
+ * rotation *= Rx(angle*pi) * Ry(angle*pi). */
+void rt_make_cube(rt_shape* out, const float center[3], const rt_material* material);
+void rt_cube_rotate(rt_shape* cube, float angle);
 /* SimpleTriangle::SimpleTriangle (shape.h:83-102). */
 void rt_make_triangle(rt_triangle* out, const float p1[3], const float p2[3],
                       const float p3[3]);

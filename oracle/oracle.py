@@ -62,6 +62,8 @@ def _load():
     lib.orc_hit_box.restype = C.c_float; lib.orc_hit_box.argtypes = [fp, C.c_float, fp, fp]
     lib.orc_hit_triangle.restype = C.c_float; lib.orc_hit_triangle.argtypes = [vp, fp, fp]
     lib.orc_box_normal.restype = None; lib.orc_box_normal.argtypes = [fp, C.c_float, fp, fp]
+    lib.orc_hit_cube.restype = C.c_int; lib.orc_hit_cube.argtypes = [fp, fp, fp, fp, fp]
+    lib.orc_cube_normal.restype = None; lib.orc_cube_normal.argtypes = [fp, fp, fp]
     lib.orc_camera_ray.restype = None; lib.orc_camera_ray.argtypes = [fp, C.POINTER(Params), u32, u32, u32, fp, fp]
     lib.orc_camera_init.restype = None; lib.orc_camera_init.argtypes = [fp, u32, u32, C.c_float, fp]
     lib.orc_make_triangle.restype = None; lib.orc_make_triangle.argtypes = [vp, fp, fp, fp]
@@ -154,6 +156,16 @@ def hit_box(center, scale, o, d):
 
 def hit_triangle(tri_rec, o, d):
     return lib.orc_hit_triangle(tri_rec.ctypes.data, _f(*o), _f(*d))
+
+
+def hit_cube(m16, o, d):
+    """-> (t, point in the cube's frame, normal) or None"""
+    t = C.c_float(); ip = _f(0, 0, 0); n = _f(0, 0, 0)
+    m = _f(*[float(x) for x in m16])
+    if not lib.orc_hit_cube(m, _f(*o), _f(*d), C.byref(t), ip):
+        return None
+    lib.orc_cube_normal(m, ip, n)
+    return t.value, np.array(ip[:], dtype=np.float32), np.array(n[:], dtype=np.float32)
 
 
 def box_normal(center, scale, p):

@@ -255,6 +255,48 @@ void orc_box_normal(const float cc[3], float scale, const float pp[3], float nn[
     nn[0] = n.x; nn[1] = n.y; nn[2] = n.z;
 }
 
+/* Cube::hit, src/cpu_version/scene.h:185-204: the CPU tracer's unit cube.  m is the
+ * shape's 4x4 transformation (column-major): rotation in the upper-left 3x3, centre in
+ * column 3.  As written there: the three slab distances are tried in axis order and the
+ * FIRST whose point lies exactly on the cube's surface (infinity norm == 0.5) is the hit,
+ * whether or not it is the nearest; divisions are IEEE.  Returns 1 and fills t and the
+ * point in the cube's frame, else 0. */
+int orc_hit_cube(const float m[16], const float oo[3], const float dd[3], float* t_out, float in_point[3])
+{
+    float oc[3] = { oo[0] - m[12], oo[1] - m[13], oo[2] - m[14] };
+    float o[3], d[3], t[3];
+    for (int i = 0; i < 3; ++i) {                                      /* rotation * (orig - center), rotation * dir   :186-187 */
+        o[i] = fmaf(m[8 + i], oc[2], fmaf(m[4 + i], oc[1], m[i] * oc[0]));
+        d[i] = fmaf(m[8 + i], dd[2], fmaf(m[4 + i], dd[1], m[i] * dd[0]));
+    }
+    for (int i = 0; i < 3; ++i) {
+        float sg = fsign(o[i]);                                        /* cwiseSign                                    :188 */
+        t[i] = (0.5f - o[i] * sg) / (sg * d[i]);                       /*                                              :190 */
+    }
+    for (int k = 0; k < 3; ++k) {                                      /*                                              :191 */
+        float px = fmaf(d[0], t[k], o[0]), py = fmaf(d[1], t[k], o[1]), pz = fmaf(d[2], t[k], o[2]);   /* :192 */
+        if (gmax(fabsf(px), gmax(fabsf(py), fabsf(pz))) == 0.5f) {     /*                                              :193 */
+            *t_out = t[k];
+            in_point[0] = px; in_point[1] = py; in_point[2] = pz;
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/* rotation^T * normalAt(inPoint), scene.h:150-164,196.  normalAt takes the sign from the
+ * maximum of the ABSOLUTE values, so it is always +1: the normal is the positive axis of
+ * the face's direction, on either side of the cube (as written).  rotation^T * e_i is row
+ * i of the rotation. */
+void orc_cube_normal(const float m[16], const float in_point[3], float nn[3])
+{
+    float ax = fabsf(in_point[0]), ay = fabsf(in_point[1]), az = fabsf(in_point[2]);
+    int i = 0; float best = ax;                                        /* maxCoeff(&index): first maximum */
+    if (ay > best) { best = ay; i = 1; }
+    if (az > best) { best = az; i = 2; }
+    nn[0] = m[i]; nn[1] = m[4 + i]; nn[2] = m[8 + i];
+}
+
 /* hitTriangle, RayTracing.glsl:179-194. */
 float orc_hit_triangle(const orc_triangle* tr, const float oo[3], const float dd[3])
 {
@@ -291,6 +333,10 @@ static float hit_shape(tracer* T, const orc_shape* s, const ray* r)
     float o[3] = { r->o.x, r->o.y, r->o.z }, d[3] = { r->d.x, r->d.y, r->d.z };
     if (s->type == 0) { T->st.sphere_tests++; return orc_hit_sphere(c, s->m[0], o, d); }
     if (s->type == 1) { T->st.box_tests++;    return orc_hit_box(c, s->m[0], o, d); }
+    if (s->type == 3 && T->p->semantics == ORC_SEM_CPU) {             /* the CPU tracer's Cube */
+        float t, ip[3];
+        return orc_hit_cube(s->m, o, d, &t, ip) ? t : INFINITY;
+    }
     return -1.0f;                                                     /* RayTracing.glsl:176 */
 }
 
@@ -365,7 +411,12 @@ static int interact_cpu(tracer* T, int index, float t, ray* r, uint32_t key, int
         type = 1;
     } else {
         const orc_shape* s = &T->shapes[index];
-        n = shape_normal(s, p);
+        if (s->type == 3) {
+            float o[3] = { r->o.x, r->o.y, r->o.z }, d[3] = { r->d.x, r->d.y, r->d.z }, tt, ip[3], nn[3];
+            orc_hit_cube(s->m, o, d, &tt, ip);
+            orc_cube_normal(s->m, ip, nn);
+            n = V(nn[0], nn[1], nn[2]);
+        } else n = shape_normal(s, p);
         albedo = V(s->mat.color[0], s->mat.color[1], s->mat.color[2]);
         type = s->mat.type; fuzz = s->mat.data[1];
     }

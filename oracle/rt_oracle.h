@@ -94,6 +94,8 @@ float    orc_hit_sphere(const float center[3], float radius, const float o[3], c
 float    orc_hit_box(const float center[3], float scale, const float o[3], const float d[3]);
 float    orc_hit_triangle(const orc_triangle* t, const float o[3], const float d[3]);
 void     orc_box_normal(const float center[3], float scale, const float p[3], float n[3]);
+int      orc_hit_cube(const float m[16], const float o[3], const float d[3], float* t, float in_point[3]);
+void     orc_cube_normal(const float m[16], const float in_point[3], float n[3]);
 void     orc_camera_ray(const float camera[21], const orc_params* p, uint32_t gx, uint32_t gy,
                         uint32_t sample, float origin[3], float dir[3]);
 

@@ -18,7 +18,7 @@ SEM_CPU, SEM_GLSL = 0, 1
 SAMPLE_JITTER, SAMPLE_GRID, SAMPLE_GRID_COMPAT = 0, 1, 2
 FLAG_METAL_UNNORMALIZED = 1
 MAT_LIGHT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DEBUG = 0, 1, 2, 3, 100
-SHAPE_CIRCLE, SHAPE_BOX = 0, 1
+SHAPE_CIRCLE, SHAPE_BOX, SHAPE_CUBE = 0, 1, 3
 
 # numpy views of the reference's struct layouts (src/gpu_version/shape.h).
 MATERIAL_DTYPE = np.dtype([("color", "<f4", 3), ("type", "<u4"), ("data", "<f4", 4)])
@@ -73,6 +73,8 @@ SIGNATURES = {
     "rt_camera_move": (None, [_fp, _u32, _u32, C.c_float, _int]),
     "rt_make_circle": (None, [_vp, _fp, C.c_float, _vp]),
     "rt_make_box": (None, [_vp, _fp, _fp, _vp]),
+    "rt_make_cube": (None, [_vp, _fp, _vp]),
+    "rt_cube_rotate": (None, [_vp, C.c_float]),
     "rt_make_triangle": (None, [_vp, _fp, _fp, _fp]),
     "rt_mesh_load": (_int, [C.POINTER(_vp), C.c_char_p]),
     "rt_mesh_free": (None, [_vp]),

@@ -238,10 +238,13 @@ static int build_blob(rt_ctx* ctx)
 {
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t n_shapes = (uint32_t)ctx->shapes.size(), n_tris = (uint32_t)ctx->tris.size();
-    uint32_t n_sph = 0, n_box = 0;
-    for (const rt_shape& s : ctx->shapes) { if (s.type == RT_SHAPE_CIRCLE) ++n_sph; else if (s.type == RT_SHAPE_BOX) ++n_box; }
+    uint32_t n_sph = 0, n_box = 0, n_cube = 0;
+    for (const rt_shape& s : ctx->shapes) {
+        if (s.type == RT_SHAPE_CIRCLE) ++n_sph; else if (s.type == RT_SHAPE_BOX) ++n_box;
+        else if (s.type == RT_SHAPE_CUBE && ctx->cfg.semantics == RT_SEM_CPU) ++n_cube;
+    }
     rtd::SceneLayout L{};
-    L.n_shapes = n_shapes; L.n_sph_pad = (n_sph + 3u) & ~3u; L.n_box = n_box; L.n_tris = n_tris;
+    L.n_shapes = n_shapes; L.n_sph_pad = (n_sph + 3u) & ~3u; L.n_box = n_box; L.n_cube = n_cube; L.n_tris = n_tris;
     L.rec_off = 0;
     L.sph_off = L.rec_off + 3u * n_shapes;
     L.sid_off = L.sph_off + L.n_sph_pad;
@@ -258,7 +261,8 @@ static int build_blob(rt_ctx* ctx)
         }
         // The top level is scanned linearly, so it is not grouped any further.
     }
-    uint32_t off = L.box_off + 2u * n_box;
+    L.cub_off = L.box_off + 2u * n_box;
+    uint32_t off = L.cub_off + 4u * n_cube;
     for (int l = (int)rtd::TREE_LEVELS - 1; l >= 0; --l) { L.node_off[l] = off; off += node_pad[l]; }
     L.inv_off = off;
     L.tri_off = L.inv_off + (n_tris + 3u) / 4u;
@@ -274,7 +278,7 @@ static int build_blob(rt_ctx* ctx)
     const float nan = std::nanf("");
     for (uint32_t i = 0; i < L.n_sph_pad; ++i) { Word& w = blob[L.sph_off + i]; w.f[0] = w.f[1] = w.f[2] = nan; w.f[3] = 0.0f; }
     for (uint32_t i = 0; i < L.n_sph_pad; ++i) as_u32(blob[L.sid_off + i / 4u].f[i % 4u]) = 0xffffffffu;
-    uint32_t is = 0, ib = 0;
+    uint32_t is = 0, ib = 0, ic = 0;
     for (uint32_t i = 0; i < n_shapes; ++i) {
         const rt_shape& s = ctx->shapes[i];
         const float cx = s.transformation[12], cy = s.transformation[13], cz = s.transformation[14];
@@ -301,6 +305,15 @@ static int build_blob(rt_ctx* ctx)
             w.f[0] = cx; w.f[1] = cy; w.f[2] = cz; w.f[3] = 1.0f / scale;
             as_u32(w1.f[0]) = i;
             ++ib;
+        } else if (s.type == RT_SHAPE_CUBE && ctx->cfg.semantics == RT_SEM_CPU) {
+            Word* w = &blob[L.cub_off + 4u * ic];
+            for (int r = 0; r < 3; ++r) {
+                w[r].f[0] = s.transformation[r]; w[r].f[1] = s.transformation[4 + r]; w[r].f[2] = s.transformation[8 + r];
+                w[r].f[3] = s.transformation[12 + r];
+            }
+            as_u32(w[3].f[0]) = i;
+            as_u32(r2.f[3]) = ic;
+            ++ic;
         }
     }
     static_assert(sizeof(rt_triangle) == 4 * sizeof(Word), "a SimpleTriangle is four 16-byte words");

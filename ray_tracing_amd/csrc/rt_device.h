@@ -16,11 +16,13 @@ namespace rtd {
 //                           word 0: centre.xyz, scale (Circle: radius, Box: side)
 //                           word 1: colour.rgb (x 0.6 for Lambertian under CPU rules), tag
 //                                   tag = material type | shape type << 16
-//                           word 2: fuzz, ior, rcp_nr(scale), unused
+//                           word 2: fuzz, ior, rcp_nr(scale), place in cub (uint32; cubes only)
 //   sph  [n_sph_pad]      spheres in upload order: centre.xyz, radius^2; padded to a
 //                         multiple of 4 with NaN centres (never hit)
 //   sid  [n_sph_pad / 4]  the spheres' shape indices, four per word
 //   box  [2 * n_box]      boxes in upload order: {centre.xyz, 1/side}, {shape index, 0, 0, 0}
+//   cub  [4 * n_cube]     the CPU tracer's cubes in upload order: rows of the rotation with the
+//                         centre, {R(i,0), R(i,1), R(i,2), c_i} for i = 0..2, then {shape index, 0, 0, 0}
 //   node [n3p+n2p+n1p+n0p] bounding spheres over the triangles, four levels (below)
 //   inv  [n_tris / 4]     for each uploaded triangle, its place in the sorted list (uint32)
 //   tri  [4 * n_tri_pad]  SimpleTriangles sorted along a space-filling curve and padded to a
@@ -35,8 +37,8 @@ namespace rtd {
 // never culled (see bound_hit in rt_kernels.hip).
 constexpr uint32_t TREE_LEAF = 4, TREE_FAN = 8, TREE_LEVELS = 4;
 struct SceneLayout {
-    uint32_t n_shapes, n_sph_pad, n_box, n_tris;
-    uint32_t rec_off, sph_off, sid_off, box_off, inv_off, tri_off;   // in 16-byte words
+    uint32_t n_shapes, n_sph_pad, n_box, n_cube, n_tris;
+    uint32_t rec_off, sph_off, sid_off, box_off, cub_off, inv_off, tri_off;   // in 16-byte words
     uint32_t node_off[TREE_LEVELS];                         // level 0 .. 3
     uint32_t node_n[TREE_LEVELS];                           // real (unpadded) node counts
     uint32_t total_words;                                   // whole blob

@@ -146,6 +146,25 @@ void rt_make_box(rt_shape* out, const float translation[3], const float sides[3]
     out->transformation[12] = translation[0]; out->transformation[13] = translation[1]; out->transformation[14] = translation[2];
 }
 
+// Cube::Cube, src/cpu_version/scene.h:144-148: identity rotation.
+void rt_make_cube(rt_shape* out, const float center[3], const rt_material* material)
+{
+    shape_base(out, RT_SHAPE_CUBE, material);
+    out->transformation[12] = center[0]; out->transformation[13] = center[1]; out->transformation[14] = center[2];
+}
+
+// Cube::rotate, scene.h:206-208: rotation *= (AngleAxisf(angle*pi, UnitX) * AngleAxisf(angle*pi, UnitY)).toRotationMatrix().
+void rt_cube_rotate(rt_shape* cube, float angle)
+{
+    if (!cube) return;
+    const float a = angle * 3.14159265358979323846f;          // `pi` is a float-converted constant there
+    const Mat3 step = mul(angle_axis(a, { 1, 0, 0 }), angle_axis(a, { 0, 1, 0 }));
+    Mat3 r;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = cube->transformation[4 * j + i];   // column-major
+    r = mul(r, step);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) cube->transformation[4 * j + i] = r.m[i][j];
+}
+
 // SimpleTriangle::SimpleTriangle, shape.h:83-102.
 void rt_make_triangle(rt_triangle* out, const float p1[3], const float p2[3], const float p3[3])
 {

@@ -258,6 +258,35 @@ RT_DEV V3 box_normal(V3 c, float rs, V3 p)
     return normalize(n);
 }
 
+// Cube::hit, src/cpu_version/scene.h:185-204, on the rows {R(i,*), c_i} of a cube.  As
+// written there: the three slab distances are tried in axis order and the first whose point
+// lies exactly on the surface (infinity norm == 0.5) is the hit, nearest or not; IEEE
+// divisions.  Returns the distance (+inf without a hit) and the point in the cube's frame.
+RT_DEV float hit_cube(float4 r0, float4 r1, float4 r2, V3 o, V3 d, V3& in_point)
+{
+    const V3 oc = v3(o.x - r0.w, o.y - r1.w, o.z - r2.w);
+    const V3 ob = v3(dot(xyz(r0), oc), dot(xyz(r1), oc), dot(xyz(r2), oc));
+    const V3 db = v3(dot(xyz(r0), d), dot(xyz(r1), d), dot(xyz(r2), d));
+    const V3 sg = v3(sign_(ob.x), sign_(ob.y), sign_(ob.z));
+    float t[3];
+    t[0] = (0.5f - ob.x * sg.x) / (sg.x * db.x);
+    t[1] = (0.5f - ob.y * sg.y) / (sg.y * db.y);
+    t[2] = (0.5f - ob.z * sg.z) / (sg.z * db.z);
+    float hit_t = __builtin_inff();
+    bool found = false;
+    in_point = v3(0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float px = fma_(db.x, t[k], ob.x), py = fma_(db.y, t[k], ob.y), pz = fma_(db.z, t[k], ob.z);
+        const bool on = gmax(__builtin_fabsf(px), gmax(__builtin_fabsf(py), __builtin_fabsf(pz))) == 0.5f;
+        const bool first = on && !found;
+        hit_t = first ? t[k] : hit_t;
+        in_point = v3(first ? px : in_point.x, first ? py : in_point.y, first ? pz : in_point.z);
+        found = found || on;
+    }
+    return hit_t;
+}
+
 // hitTriangle, RayTracing.glsl:179-194, on the four words of a SimpleTriangle
 // (w0.w carries the triangle's index in the uploaded array).  The early return
 // for k < 0 (:182-184) is left to the window test, which rejects every negative k.
@@ -299,8 +328,9 @@ RT_DEV uint32_t quantise(float c)
 // -------------------------------------------------------------- the tracer
 // SEM 0: rules of src/cpu_version (rayTracer.h:110-132, scene.h:39-109).
 // SEM 1: rules of RayTracing.glsl:233-288.
-// TRI_GLOBAL: the triangles did not fit into LDS and are read from the blob in
-// global memory.  MODE 0: render.  MODE 1: render and count work.  MODE 2:
+// GEO bit 0: the triangles did not fit into LDS and are read from the blob in
+// global memory; bit 1: the scene holds cubes of the CPU tracer (kept out of the
+// other instances, whose registers they would cost).  MODE 0: render.  MODE 1: render and count work.  MODE 2:
 // follow one sample, record hit and material ids, leave the accumulator alone.
 //
 // One loop iteration = one ray segment of every live lane: closest hit, then
@@ -308,8 +338,8 @@ RT_DEV uint32_t quantise(float c)
 // same iteration, and the two expensive steps every continuing lane needs —
 // two random draws and the normalisation of the new direction — are issued
 // once for the whole wave, whether a lane is bouncing or starting a sample.
-template <int SEM, bool TRI_GLOBAL, int MODE>
-__global__ __launch_bounds__(BLOCK)
+template <int SEM, int GEO, int MODE>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void trace_kernel(const TraceParams P,
                   const float4* __restrict__ blob,
                   uint32_t* __restrict__ accum,
@@ -320,6 +350,7 @@ void trace_kernel(const TraceParams P,
                   uint32_t* __restrict__ tile_cost)
 {
     constexpr bool STATS = MODE == 1, TRACE = MODE == 2;
+    constexpr bool TRI_GLOBAL = (GEO & 1) != 0, HAS_CUBE = SEM == 0 && (GEO & 2) != 0;
     extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < P.scene.lds_words; i += BLOCK) lds[i] = blob[i];
@@ -406,6 +437,7 @@ void trace_kernel(const TraceParams P,
     const float4* const sid = lds + L.sid_off;
     const float4* const box = lds + L.box_off;
     const float4* const rec = lds + L.rec_off;
+    const float4* const cub = lds + L.cub_off;
     const float4* const tri = TRI_GLOBAL ? blob + L.tri_off : lds + L.tri_off;
     const uint32_t* const slot_of = reinterpret_cast<const uint32_t*>(TRI_GLOBAL ? blob + L.inv_off : lds + L.inv_off);
     const float4* const node0 = lds + L.node_off[0];
@@ -441,6 +473,13 @@ void trace_kernel(const TraceParams P,
             const float4 bx = box[2u * i];
             const uint32_t bid = __float_as_uint(box[2u * i + 1u].x);
             take_if_closer(best, __float_as_uint(hit_box(bx, o, d)) - Window<SEM>::tmin, bid);
+        }
+        if (HAS_CUBE) {
+            for (uint32_t i = 0; i < L.n_cube; ++i) {
+                V3 ip;
+                const float t = hit_cube(cub[4u * i], cub[4u * i + 1u], cub[4u * i + 2u], o, d, ip);
+                take_if_closer(best, __float_as_uint(t) - Window<SEM>::tmin, __float_as_uint(cub[4u * i + 3u].x));
+            }
         }
         // Triangles: walk the four-level bounding-sphere tree with the whole wave; a
         // subtree is entered when the ray of any live lane can touch its sphere.
@@ -497,6 +536,20 @@ void trace_kernel(const TraceParams P,
                 att = xyz(r1);
                 if (stype == 0u) n = normalize(v3(p.x - r0.x, p.y - r0.y, p.z - r0.z));      // scene.h:130-132
                 else if (stype == 1u) n = box_normal(xyz(r0), rec[3u * best_id + 2u].z, p);
+                else if (HAS_CUBE && stype == 3u) {
+                    // rotation^T * normalAt(inPoint), scene.h:150-164,196: the row of the rotation that
+                    // belongs to the largest |coordinate| of the point in the cube's frame (first of
+                    // equals); the sign there is taken from an absolute value, so it is always +.
+                    const uint32_t ci = 4u * __float_as_uint(rec[3u * best_id + 2u].w);
+                    const float4 c0 = cub[ci], c1 = cub[ci + 1u], c2 = cub[ci + 2u];
+                    V3 ip;
+                    (void)hit_cube(c0, c1, c2, o, d, ip);
+                    const float ax = __builtin_fabsf(ip.x), ay = __builtin_fabsf(ip.y), az = __builtin_fabsf(ip.z);
+                    const bool y_gt = ay > ax;
+                    const float m1 = y_gt ? ay : ax;
+                    const bool z_gt = az > m1;
+                    n = z_gt ? xyz(c2) : (y_gt ? xyz(c1) : xyz(c0));
+                }
                 else n = v3(1.0f, 1.0f, 1.0f);                        // glsl:203
                 if (SEM == 0 && type == 2u) fuzz = rec[3u * best_id + 2u].x;
             }
@@ -770,12 +823,12 @@ __global__ void convert_kernel(uint32_t* __restrict__ accum, float* __restrict__
 
 // ------------------------------------------------------------ host launchers
 
-template <int SEM, bool TG, int MODE>
+template <int SEM, int GEO, int MODE>
 static hipError_t launch_one(dim3 grid, size_t lds_bytes, hipStream_t stream, const TraceParams& P, const float4* blob,
                              uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm,
                              const uint32_t* tile_order, uint32_t* tile_cost)
 {
-    hipLaunchKernelGGL((trace_kernel<SEM, TG, MODE>), grid, dim3(BLOCK), lds_bytes, stream, P, blob, accum, st, th, tm,
+    hipLaunchKernelGGL((trace_kernel<SEM, GEO, MODE>), grid, dim3(BLOCK), lds_bytes, stream, P, blob, accum, st, th, tm,
                        tile_order, tile_cost);
     return hipGetLastError();
 }
@@ -795,12 +848,12 @@ hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams
     const dim3 grid(P.tiles_x * P.tiles_y);
     const float4* b = static_cast<const float4*>(blob);
     const size_t lds_bytes = (size_t)P.scene.lds_words * 16u;
-    const bool tg = P.scene.n_tris != 0 && !P.scene.tri_in_lds;
-#define RT_CASE(S, T, M) if (sem == S && tg == T && mode == M) return launch_one<S, T, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm, tile_order, tile_cost)
-    RT_CASE(0, false, 0); RT_CASE(0, false, 1); RT_CASE(0, false, 2);
-    RT_CASE(0, true, 0);  RT_CASE(0, true, 1);  RT_CASE(0, true, 2);
-    RT_CASE(1, false, 0); RT_CASE(1, false, 1); RT_CASE(1, false, 2);
-    RT_CASE(1, true, 0);  RT_CASE(1, true, 1);  RT_CASE(1, true, 2);
+    const int geo = ((P.scene.n_tris != 0 && !P.scene.tri_in_lds) ? 1 : 0) | ((sem == 0 && P.scene.n_cube != 0) ? 2 : 0);
+#define RT_CASE(S, G, M) if (sem == S && geo == G && mode == M) return launch_one<S, G, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm, tile_order, tile_cost)
+#define RT_CASES(S, G) RT_CASE(S, G, 0); RT_CASE(S, G, 1); RT_CASE(S, G, 2)
+    RT_CASES(0, 0); RT_CASES(0, 1); RT_CASES(0, 2); RT_CASES(0, 3);
+    RT_CASES(1, 0); RT_CASES(1, 1);
+#undef RT_CASES
 #undef RT_CASE
     return hipErrorInvalidValue;
 }

@@ -77,6 +77,15 @@ class Box(Shape):                           # shape.h:64-70
         lib.rt_make_box(self.rec.ctypes.data, _abi.f3(translation), _abi.f3(sides), material.rec.ctypes.data)
 
 
+class Cube(Shape):                          # the CPU tracer's Cube, src/cpu_version/scene.h:142-217
+    def __init__(self, center, material):
+        super().__init__()
+        lib.rt_make_cube(self.rec.ctypes.data, _abi.f3(center), material.rec.ctypes.data)
+
+    def rotate(self, angle):                # scene.h:206-208
+        lib.rt_cube_rotate(self.rec.ctypes.data, float(angle))
+
+
 class SimpleTriangle:                       # shape.h:81-109
     def __init__(self, p1, p2, p3):
         self.rec = np.zeros((), dtype=TRIANGLE_DTYPE)

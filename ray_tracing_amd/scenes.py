@@ -60,6 +60,17 @@ def cpu_sphere_scene(with_metal=False, extra_lights=False):
     return _shapes(objs)
 
 
+def cpu_tracer_scene(cube_turns=3):
+    """The whole scene of the CPU tracer, src/cpu_version/rayTracer.h:48-61: four spheres, the fuzzy
+    metal sphere and the Lambertian cube, the cube turned `cube_turns` times by rotate(0.1) as
+    render() does once per frame (rayTracer.h:82)."""
+    L = host.Lambertian
+    cube = host.Cube((-1.5, 0.5, -4), L((0.5, 0.5, 1)))                                  # :61
+    for _ in range(cube_turns):
+        cube.rotate(0.1)
+    return np.concatenate([cpu_sphere_scene(with_metal=True), _shapes([cube])])
+
+
 def main_cpp_shapes():
     """The nine shapes of src/main.cpp:95-106."""
     L, M, Li = host.Lambertian, host.Metal, host.Light
@@ -154,7 +165,15 @@ def config5(width=2048, height=2048, spp=64, max_depth=16):
                        _camera(width, height, (1, 1.5, 6)), width, height, spp, max_depth, SEM_CPU)
 
 
-CONFIGS = {"c1": config1, "c2": config2, "c3": config3, "c4": config4, "c5": config5}
+def config_cpu_tracer(width=512, height=512, spp=25, max_depth=11, cube_turns=3):
+    """rayTracer.h as shipped: its full scene, 5 x 5 samples on the grid of renderPixel<5> as written
+    (x offset accumulating), 10 + 1 segments (rayTracer.h:78,113)."""
+    return SceneConfig("cpu_tracer_as_shipped", cpu_tracer_scene(cube_turns), np.zeros(0, TRIANGLE_DTYPE),
+                       _camera(width, height, (1, 0, 6)), width, height, spp, max_depth, SEM_CPU,
+                       sample_mode=_abi.SAMPLE_GRID_COMPAT)
+
+
+CONFIGS = {"cpu_tracer": config_cpu_tracer, "c1": config1, "c2": config2, "c3": config3, "c4": config4, "c5": config5}
 
 
 def make_renderer(cfg, device=0):

@@ -23,10 +23,11 @@ import ray_tracing_amd as rta          # host-side constructors only (no GPU nee
 from oracle import oracle as orc
 
 W, H, SPP = 64, 36, 16
-DEPTHS = {"c1": 4, "c2": 8, "c3": 10, "c4": 11, "c5": 16}
+DEPTHS = {"c1": 4, "c2": 8, "c3": 10, "c4": 11, "c5": 16, "cpu_tracer": 11}
 
 
 def scene(name):
+    # "cpu_tracer" samples on renderPixel<N>'s grid: 16 = 4 x 4
     return rta.scenes.CONFIGS[name](width=W, height=H, spp=SPP, max_depth=DEPTHS[name])
 
 
@@ -44,7 +45,7 @@ def main():
                         draws=draws, hashes=hashes, u=us, sincos=sincos, unit_vector=unit, hemisphere=hemi)
 
     # (ii)+(iii) per configuration scene at 64x36, 16 spp: accumulator words, counters, per-bounce hit / material ids
-    for name in ("c1", "c2", "c3", "c4", "c5"):
+    for name in ("c1", "c2", "c3", "c4", "c5", "cpu_tracer"):
         cfg = scene(name)
         p = orc.params(W, H, SPP, cfg.max_depth, seed=cfg.seed, semantics=cfg.semantics, sample_mode=cfg.sample_mode,
                        flags=cfg.flags, triangle_albedo=cfg.triangle_albedo)

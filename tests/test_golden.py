@@ -13,8 +13,8 @@ import pytest
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 W, H, SPP = 64, 36, 16
-DEPTHS = {"c1": 4, "c2": 8, "c3": 10, "c4": 11, "c5": 16}
-CONFIGS = ("c1", "c2", "c3", "c4", "c5")
+DEPTHS = {"c1": 4, "c2": 8, "c3": 10, "c4": 11, "c5": 16, "cpu_tracer": 11}
+CONFIGS = ("c1", "c2", "c3", "c4", "c5", "cpu_tracer")
 
 
 def load(name):
@@ -77,12 +77,13 @@ def test_hip_path_reproduces_scene_fixture(rta, name):
     cfg = scene(rta, name)
     rt = rta.scenes.make_renderer(cfg)
     try:
-        st = rt.render(W, H, SPP, cfg.max_depth, cfg.seed, stats=True)
+        grid_n = 4 if cfg.sample_mode != rta.SAMPLE_JITTER else 0          # 16 samples = renderPixel<4>'s grid
+        st = rt.render(W, H, SPP, cfg.max_depth, cfg.seed, grid_n=grid_n, stats=True)
         img = rt.resolve(W, H, gamma_sqrt=(cfg.semantics == 0))
         np.testing.assert_array_equal(img.view(np.uint32), g["image"].view(np.uint32))
         assert [st[k] for k in ("samples", "segments", "diffuse", "specular", "terminal")] == list(g["counters"])
         for s, tag in ((0, "s0"), (9, "s9")):
-            hit, mat = rt.traceDebug(W, H, cfg.max_depth, cfg.seed, s)
+            hit, mat = rt.traceDebug(W, H, cfg.max_depth, cfg.seed, s, grid_n=grid_n)
             np.testing.assert_array_equal(hit, g["hit_" + tag]); np.testing.assert_array_equal(mat, g["mat_" + tag])
     finally:
         rt.close()

@@ -78,6 +78,18 @@ def test_config5_divergence_scene(rta, orc):
     check_config(rta, orc, rta.scenes.config5(width=128, height=128, spp=8, max_depth=16), trace_samples=(3,))
 
 
+def test_cpu_tracer_scene_as_shipped(rta, orc):
+    """rayTracer.h:48-61 in full — spheres, fuzzy metal and the rotated Cube (scene.h:142-217) — on the 5 x 5 grid
+    of renderPixel<5> as written, 11 segments."""
+    st = check_config(rta, orc, rta.scenes.config_cpu_tracer(width=160, height=160), trace_samples=(0, 12, 24), grid_n=5)
+    hit, _ = None, None
+    cfg = rta.scenes.config_cpu_tracer(width=160, height=160)
+    rt = rta.scenes.make_renderer(cfg)
+    hit, mat = rt.traceDebug(160, 160, 11, cfg.seed, 0, grid_n=5)
+    rt.close()
+    assert (hit == 5).sum() > 50          # the cube (shape 5) is hit by some rays; its exact surface test passes only sometimes
+
+
 def test_metal_unnormalized_flag(rta, orc):
     cfg = rta.scenes.config4(width=96, height=54, spp=8, max_depth=11)
     cfg.flags = rta.FLAG_METAL_UNNORMALIZED

@@ -100,6 +100,35 @@ def test_hit_box_closed_forms(orc):
     assert abs(orc.hit_box((-1, 12, -2), 10.0, (-1, 0, -2.5), (0, 1, 0)) - 7.0) < 1e-5
 
 
+def test_hit_cube_closed_forms(rta, orc):
+    """Cube::hit of the CPU tracer (scene.h:185-204): unit cube, exact == 0.5 surface test, + axis normal."""
+    ident = np.eye(4, dtype=np.float32).T.reshape(-1)
+    t, ip, n = orc.hit_cube(ident, (0, 0, 5), (0, 0, -1))
+    assert t == 4.5 and tuple(ip) == (0, 0, 0.5) and tuple(n) == (0, 0, 1)
+    t, ip, n = orc.hit_cube(ident, (0, 0, -5), (0, 0, 1))
+    assert t == 4.5 and tuple(ip) == (0, 0, -0.5) and tuple(n) == (0, 0, 1)      # sign from an absolute value: always +
+    t, ip, n = orc.hit_cube(ident, (0.25, 3, 0.125), (0, -1, 0))
+    assert t == 2.5 and tuple(n) == (0, 1, 0)
+    assert orc.hit_cube(ident, (2, 0, 5), (0, 0, -1)) is None                     # passes beside
+    c = rta.Cube((1, 2, 3), rta.Lambertian((1, 1, 1)))
+    m = c.rec["transformation"]
+    t, ip, n = orc.hit_cube(m, (1, 2, 8), (0, 0, -1))
+    assert t == 4.5 and tuple(n) == (0, 0, 1)
+    # rotate(0.5): Rx(pi/2) * Ry(pi/2); the matrix stays orthonormal and the normal is a row of it
+    c.rotate(0.5)
+    R = c.transformation[:3, :3].astype(np.float64)
+    np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-6)
+    hits = 0
+    rng = np.random.RandomState(4)
+    for _ in range(400):
+        o = rng.uniform(-0.3, 0.3, 3) + np.array([1, 2, 8]); d = np.array([1, 2, 3]) - o + rng.uniform(-0.2, 0.2, 3); d /= np.linalg.norm(d)
+        r = orc.hit_cube(c.rec["transformation"], tuple(o.astype(np.float32)), tuple(d.astype(np.float32)))
+        if r is not None:
+            hits += 1
+            assert abs(np.abs(r[1]).max() - 0.5) == 0 and any(np.allclose(r[2], R[i], atol=1e-6) for i in range(3))
+    assert hits > 20            # the exact == 0.5 test of scene.h:193 passes only now and then
+
+
 def test_hit_triangle_closed_forms(orc):
     inf = float("inf")
     t = orc.make_triangle((0, 0, 0), (1, 0, 0), (0, 1, 0))
