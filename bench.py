@@ -4,7 +4,8 @@
     python bench.py --gpus N --steps K --warmup W
 
 A step is one full frame of the workload: clear the accumulator, trace `spp` samples per pixel, sum the
-ranks' accumulators (RCCL) when N > 1, resolve on rank 0.  The scene and camera are resident in HBM
+ranks' accumulators (RCCL) when N > 1, resolve on rank 0.  With N > 1 consecutive frames use two
+accumulators in turn, so that one frame's exchange runs beside the next frame's trace.  The scene and camera are resident in HBM
 before the timed region.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
 traces its own `spp` samples of every pixel (disjoint sample ranges -> weak scaling: the frame gains
 N x spp samples per pixel), or, with --shard rows, its own interleaved bands of rows.
@@ -97,38 +98,61 @@ def main():
     if args.spp:
         cfg.spp = args.spp
     shard = parallel.plan(args.shard, rank, world, cfg.spp)
-    rt = rta.scenes.make_renderer(cfg, device=local_rank)
-    rt.setStream(torch.cuda.current_stream().cuda_stream)
-    parallel.apply(rt, shard)
-    accum = torch.zeros(cfg.height, cfg.width, 4, dtype=torch.int32, device="cuda")
+    # With several GPUs consecutive frames alternate between two accumulators (and two contexts bound to
+    # them), so that the framebuffer exchange of frame k runs beside the trace of frame k+1.
+    n_buf = 2 if world > 1 else 1
+    rts, accums = [], []
+    for _ in range(n_buf):
+        rt = rta.scenes.make_renderer(cfg, device=local_rank)
+        rt.setStream(torch.cuda.current_stream().cuda_stream)
+        parallel.apply(rt, shard)
+        accum = torch.zeros(cfg.height, cfg.width, 4, dtype=torch.int32, device="cuda")
+        rt.bindAccum(accum.data_ptr(), cfg.width, cfg.height)
+        rts.append(rt); accums.append(accum)
     out = torch.empty(cfg.height, cfg.width, 4, dtype=torch.float32, device="cuda")
-    rt.bindAccum(accum.data_ptr(), cfg.width, cfg.height)
 
-    def step(ev=None):
+    def trace(k, ev=None):
+        rt = rts[k % n_buf]
         rt.resetAccum()                       # hipMemsetAsync of the bound accumulator on the stream
         if ev:
             ev[0].record()
         rt.render(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, first_sample=shard.first_sample)
         if ev:
             ev[1].record()
-        parallel.reduce_framebuffer(accum, cfg.semantics)
+        return k, parallel.reduce_framebuffer(accums[k % n_buf], cfg.semantics, async_op=True)
+
+    def finish(pending):
+        k, work = pending
+        if work is not None:
+            work.wait()                       # the current stream waits for the collective
         if rank == 0:
+            rt = rts[k % n_buf]
             rt.setAccumSamples(parallel.total_samples(shard))
             rt.resolveDevice(out.data_ptr(), gamma_sqrt=(cfg.semantics == rta.SEM_CPU), flip_rows=True)
 
-    # Work counters of one launch (same inputs every step -> same counts); not timed.
-    rt.resetAccum()
-    stats = rt.render(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, first_sample=shard.first_sample, stats=True)
+    def run(n, events=None):
+        pending = None
+        for k in range(n):
+            nxt = trace(k, events[k] if events else None)
+            if pending is not None:
+                finish(pending)               # frame k-1: after frame k's trace is queued
+            if n_buf == 1:
+                finish(nxt); nxt = None
+            pending = nxt
+        if pending is not None:
+            finish(pending)
 
-    for _ in range(args.warmup):
-        step()
+    # Work counters of one launch (same inputs every step -> same counts); not timed.
+    rts[0].resetAccum()
+    stats = rts[0].render(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, first_sample=shard.first_sample, stats=True)
+
+    run(args.warmup)
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
+    run(args.steps, events)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -185,8 +209,9 @@ def main():
             result["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(result), flush=True)
 
-    rt.bindAccum(None, 0, 0)
-    rt.close()
+    for rt in rts:
+        rt.bindAccum(None, 0, 0)
+        rt.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -62,8 +62,12 @@ def accum_view(accum_words, semantics):
     return accum_words.view(torch.float32) if semantics == SEM_CPU else accum_words
 
 
-def reduce_framebuffer(accum_words, semantics, dst=0, group=None):
-    """Sum the ranks' accumulators into rank `dst` (in place there)."""
+def reduce_framebuffer(accum_words, semantics, dst=0, group=None, async_op=False):
+    """Sum the ranks' accumulators into rank `dst` (in place there).
+
+    With async_op the collective is only queued (behind the work already on the current stream) and
+    its handle returned: the caller can launch the next frame's trace before calling .wait(), so
+    that the exchange over xGMI runs beside it."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return
-    dist.reduce(accum_view(accum_words, semantics), dst=dst, op=dist.ReduceOp.SUM, group=group)
+        return None
+    return dist.reduce(accum_view(accum_words, semantics), dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
