@@ -174,7 +174,7 @@ private:
 class RayTracingComputeShader {
 public:
     explicit RayTracingComputeShader(Camera& camera, int device = 0, rt_semantics semantics = RT_SEM_GLSL,
-                                     rt_sample_mode sampleMode = RT_SAMPLE_JITTER, unsigned int flags = 0)
+                                     rt_sample_mode sampleMode = RT_SAMPLE_JITTER, unsigned int flags = 0, rt_rng rng = RT_RNG_HASH)
         : camera(camera)
     {
         rt_config cfg{};
@@ -183,6 +183,7 @@ public:
         cfg.semantics = semantics;
         cfg.sample_mode = sampleMode;
         cfg.flags = flags;
+        cfg.rng = rng;
         cfg.triangle_albedo[0] = 1.0f;                          // RayTracing.glsl:275
         if (rt_create(&ctx, &cfg) != RT_OK) throw std::runtime_error(rt_last_error(nullptr));
     }

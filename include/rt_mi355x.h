@@ -101,6 +101,19 @@ enum rt_flags {
     RT_FLAG_METAL_UNNORMALIZED = 1u << 0
 };
 
+/* Which stream feeds the random draws. */
+enum rt_rng {
+    /* Counter based: draw i of the path (seed, pixel, sample) is a hash of those four numbers.
+     * Stands in for both reference generators, neither of which can be replayed (src/utils.h:8-9:
+     * an unseeded mt19937 shared by racing threads; RayTracing.glsl:8-9: wall-clock time). */
+    RT_RNG_HASH = 0,
+    /* The shader's own random() (RayTracing.glsl:44-51) with its seed of RayTracing.glsl:9:
+     * sample s of a pixel is invocation (s % 10, s / 10 % 10) of the pixel's 10 x 10 work group
+     * in frame s / 100, `time` = (seed + frame) / 10000 (main.cpp:139-141 passes milliseconds /
+     * 10000), and draws are consumed in the order the shader's program makes them. */
+    RT_RNG_GLSL = 1
+};
+
 enum rt_status {
     RT_OK                 =  0,
     RT_ERR_INVALID_ARG    = -1,
@@ -118,6 +131,7 @@ typedef struct rt_config {
     uint32_t sample_mode;      /* enum rt_sample_mode                            */
     uint32_t flags;            /* enum rt_flags                                  */
     float    triangle_albedo[3]; /* RayTracing.glsl:275 hard-codes (1,0,0)       */
+    uint32_t rng;              /* enum rt_rng                                    */
 } rt_config;
 
 /* Work counters of the last rt_render call that asked for them. */

@@ -16,6 +16,7 @@ SEM_CPU, SEM_GLSL = 0, 1
 SAMPLE_JITTER, SAMPLE_GRID, SAMPLE_GRID_COMPAT = 0, 1, 2
 COLOR_AS_WRITTEN, COLOR_FORWARD = 0, 1
 UNIT_DIRECT, UNIT_GAUSS = 0, 1
+RNG_HASH, RNG_GLSL = 0, 1
 
 
 class Params(C.Structure):
@@ -24,7 +25,7 @@ class Params(C.Structure):
                 ("semantics", C.c_uint32), ("sample_mode", C.c_uint32), ("flags", C.c_uint32),
                 ("triangle_albedo", C.c_float * 3), ("color_order", C.c_uint32), ("unit_sampler", C.c_uint32),
                 ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("band_rows", C.c_uint32),
-                ("threads", C.c_int32)]
+                ("threads", C.c_int32), ("rng", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -55,6 +56,8 @@ def _load():
     lib.orc_hash32.restype = u32; lib.orc_hash32.argtypes = [u32]
     lib.orc_path_key.restype = u32; lib.orc_path_key.argtypes = [u64, u32, u32]
     lib.orc_draw.restype = C.c_float; lib.orc_draw.argtypes = [u32, u32]
+    lib.orc_glsl_random.restype = C.c_float; lib.orc_glsl_random.argtypes = [fp]
+    lib.orc_glsl_seed.restype = None; lib.orc_glsl_seed.argtypes = [u64, u32, u32, u32, u32, u32, fp]
     lib.orc_sincos2pi.restype = None; lib.orc_sincos2pi.argtypes = [C.c_float, fp, fp]
     lib.orc_unit_vector.restype = None; lib.orc_unit_vector.argtypes = [C.c_float, C.c_float, fp]
     lib.orc_hemisphere_glsl.restype = None; lib.orc_hemisphere_glsl.argtypes = [fp, C.c_float, C.c_float, fp]
@@ -85,9 +88,9 @@ def _fp(a):
 
 def params(width, height, spp, max_depth, seed=1, semantics=SEM_CPU, sample_mode=SAMPLE_JITTER, flags=0,
            first_sample=0, grid_n=0, triangle_albedo=(1.0, 0.0, 0.0), color_order=COLOR_FORWARD,
-           unit_sampler=UNIT_DIRECT, shard=(0, 1, 16), threads=0):
+           unit_sampler=UNIT_DIRECT, shard=(0, 1, 16), threads=0, rng=RNG_HASH):
     return Params(width, height, spp, first_sample, max_depth, grid_n, seed, semantics, sample_mode, flags,
-                  (C.c_float * 3)(*triangle_albedo), color_order, unit_sampler, shard[0], shard[1], shard[2], threads)
+                  (C.c_float * 3)(*triangle_albedo), color_order, unit_sampler, shard[0], shard[1], shard[2], threads, rng)
 
 
 def render(shapes, triangles, camera, p, accum=None):

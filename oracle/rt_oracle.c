@@ -119,6 +119,47 @@ float orc_draw(uint32_t key, uint32_t index)
     return (float)(h >> 8) * 0x1p-24f;
 }
 
+/* random() of RayTracing.glsl:44-51, the shader's own stream: the state is the vec3 `seed`
+ * (RayTracing.glsl:9: time + global invocation id / number of work groups), every draw adds
+ * (1.78, 3.1, 50.78) to it and returns fract(sin(dot(seed, (12.9898, 78.233, 51.112))) *
+ * 43758.5453123).  The sine is taken of the angle reduced to one turn, by the same polynomial
+ * as everywhere else here; a GL driver's own sine of arguments in the thousands is no better
+ * defined.  Draws are consumed in program order, so the state travels with the path. */
+float orc_glsl_random(float seed[3])
+{
+    seed[0] = seed[0] + 1.78f; seed[1] = seed[1] + 3.1f; seed[2] = seed[2] + 50.78f;      /* :47 */
+    float x = fmaf(seed[2], 51.112f, fmaf(seed[1], 78.233f, seed[0] * 12.9898f));          /* dot  :48 */
+    float t = x * 0x1.45f306p-3f;                                                          /* x / (2 pi) */
+    float u = t - floorf(t);
+    float c, sn;
+    orc_sincos2pi(u, &c, &sn);
+    float v = sn * 43758.5453123f;
+    return v - floorf(v);                                                                  /* fract */
+}
+
+/* The state of one path's stream: the counter key of the default generator, or the vec3
+ * seed of the shader's. */
+typedef struct { uint32_t key; uint32_t glsl; float s[3]; } pathrng;
+
+static inline float rdraw(pathrng* g, uint32_t index)
+{
+    return g->glsl ? orc_glsl_random(g->s) : orc_draw(g->key, index);
+}
+
+/* RayTracing.glsl:9 for sample `sample` of pixel (gx, gy): the frame is sample / 100, the
+ * local invocation (sample % 10, sample / 10 % 10) of the pixel's 10 x 10 work group
+ * (RayTracing.glsl:2,6); `time` (main.cpp:139-141: milliseconds / 10000) is (seed + frame)
+ * / 10000. */
+void orc_glsl_seed(uint64_t seed, uint32_t width, uint32_t height, uint32_t gx, uint32_t gy, uint32_t sample, float out[3])
+{
+    uint32_t frame = sample / 100u, lx = sample % 10u, ly = (sample / 10u) % 10u;
+    float time = (float)(uint32_t)(seed + frame) * 0.0001f;
+    float inv_w = 1.0f / (float)width, inv_h = 1.0f / (float)height;
+    out[0] = time + (float)(10u * gx + lx) * inv_w;
+    out[1] = time + (float)(10u * gy + ly) * inv_h;
+    out[2] = time;
+}
+
 /* Draw numbering inside one path: 0,1 = sub-pixel jitter (RayTracing.glsl:296,
  * first draw goes with `right`, second with `up`); bounce b owns draws
  * 2+4b .. 5+4b. */
@@ -170,10 +211,10 @@ void orc_unit_vector(float u1, float u2, float out[3])
 /* utils.h:45 literally: three N(0,1) deviates, normalised.  The deviates come
  * from Box-Muller on four draws, the construction the reference itself writes
  * in RayTracing.glsl:53-62.  libm; statistical cross-check only. */
-static v3 unit_vector_gauss(uint32_t key, uint32_t base)
+static v3 unit_vector_gauss(pathrng* g, uint32_t base)
 {
-    float u1 = orc_draw(key, base), u2 = orc_draw(key, base + 1);
-    float u3 = orc_draw(key, base + 2), u4 = orc_draw(key, base + 3);
+    float u1 = rdraw(g, base), u2 = rdraw(g, base + 1);
+    float u3 = rdraw(g, base + 2), u4 = rdraw(g, base + 3);
     if (u1 < 0x1p-24f) u1 = 0x1p-24f;
     if (u3 < 0x1p-24f) u3 = 0x1p-24f;
     float r1 = sqrtf(-2.0f * logf(u1)), r2 = sqrtf(-2.0f * logf(u3));
@@ -385,11 +426,12 @@ static v3 shape_normal(const orc_shape* s, v3 p)
     return V(1.0f, 1.0f, 1.0f);                                       /* glsl:203 */
 }
 
-static v3 unit_vector(tracer* T, uint32_t key, uint32_t base)
+static v3 unit_vector(tracer* T, pathrng* g, uint32_t base)
 {
-    if (T->p->unit_sampler == ORC_UNIT_GAUSS) return unit_vector_gauss(key, base);
+    if (T->p->unit_sampler == ORC_UNIT_GAUSS) return unit_vector_gauss(g, base);
     float u[3];
-    orc_unit_vector(orc_draw(key, base), orc_draw(key, base + 1), u);
+    float u1 = rdraw(g, base), u2 = rdraw(g, base + 1);
+    orc_unit_vector(u1, u2, u);
     return V(u[0], u[1], u[2]);
 }
 
@@ -399,7 +441,7 @@ enum { EV_SCATTER = 0, EV_EMIT = 1 };
 /* One hit under the CPU tracer's rules: Material::scatter / emit,
  * scene.h:39-109.  On EV_SCATTER `att` is the attenuation and *r the new ray;
  * on EV_EMIT `att` is what the path returns at this hit. */
-static int interact_cpu(tracer* T, int index, float t, ray* r, uint32_t key, int bounce, v3* att, uint32_t* mat_id)
+static int interact_cpu(tracer* T, int index, float t, ray* r, pathrng* key, int bounce, v3* att, uint32_t* mat_id)
 {
     v3 p = madd(t, r->d, r->o);                                        /* Ray::at, scene.h:21-23 */
     v3 n; v3 albedo; uint32_t type; float fuzz = 0.0f;
@@ -448,7 +490,7 @@ static int interact_cpu(tracer* T, int index, float t, ray* r, uint32_t key, int
 
 /* ray_color, rayTracer.h:110-132, as written: recursive; the products are
  * formed on the way back out. */
-static v3 ray_color_cpu_recursive(tracer* T, ray r, int depth, uint32_t key, int bounce)
+static v3 ray_color_cpu_recursive(tracer* T, ray r, int depth, pathrng* key, int bounce)
 {
     if (depth < 0) { T->st.terminal++; return V(0, 0, 0); }            /* :113-115 */
     float t; T->st.segments++;
@@ -465,7 +507,7 @@ static v3 ray_color_cpu_recursive(tracer* T, ray r, int depth, uint32_t key, int
 }
 
 /* The same paths with the products formed camera-outwards. */
-static v3 ray_color_cpu_forward(tracer* T, ray r, int max_depth, uint32_t key)
+static v3 ray_color_cpu_forward(tracer* T, ray r, int max_depth, pathrng* key)
 {
     v3 thr = V(1, 1, 1);
     for (int bounce = 0; bounce < max_depth; ++bounce) {
@@ -487,7 +529,7 @@ static v3 ray_color_cpu_forward(tracer* T, ray r, int max_depth, uint32_t key)
 }
 
 /* ray_color + scatter, RayTracing.glsl:233-288. */
-static v3 ray_color_glsl(tracer* T, ray r, int max_depth, uint32_t key)
+static v3 ray_color_glsl(tracer* T, ray r, int max_depth, pathrng* key)
 {
     v3 result = V(1, 1, 1);                                            /* :258 */
     for (int bounce = 0; bounce < max_depth; ++bounce) {               /* :263 */
@@ -495,12 +537,12 @@ static v3 ray_color_glsl(tracer* T, ray r, int max_depth, uint32_t key)
         int index = closest_hit(T, &r, &t);                            /* :264-265 */
         if (T->trace_hit) T->trace_hit[bounce] = index;
         if (index < 0) { T->st.terminal++; return V(0, 0, 0); }        /* :267-269 */
-        float u1 = orc_draw(key, DRAW_BOUNCE(bounce)), u2 = orc_draw(key, DRAW_BOUNCE(bounce) + 1);
         if (index >= (int)T->n_shapes) {                               /* :271-277 */
             const orc_triangle* tr = &T->tris[index - (int)T->n_shapes];
             v3 a = V(tr->a[0], tr->a[1], tr->a[2]);
             v3 n = vscale(a, fsign(-dot(r.d, a)));                     /* :272 */
             r.o = madd(t, r.d, r.o);                                   /* :273 */
+            float u1 = rdraw(key, DRAW_BOUNCE(bounce)), u2 = rdraw(key, DRAW_BOUNCE(bounce) + 1);   /* :66-67, in that order */
             float nn[3] = { n.x, n.y, n.z }, out[3];
             orc_hemisphere_glsl(nn, u1, u2, out);                      /* :274 */
             r.d = V(out[0], out[1], out[2]);
@@ -517,6 +559,7 @@ static v3 ray_color_glsl(tracer* T, ray r, int max_depth, uint32_t key)
         if (type == 1) {                                               /* :238-242 */
             r.o = madd(t, r.d, r.o);
             v3 n = shape_normal(s, r.o);
+            float u1 = rdraw(key, DRAW_BOUNCE(bounce)), u2 = rdraw(key, DRAW_BOUNCE(bounce) + 1);
             float nn[3] = { n.x, n.y, n.z }, out[3];
             orc_hemisphere_glsl(nn, u1, u2, out);
             r.d = V(out[0], out[1], out[2]);
@@ -559,17 +602,19 @@ static v3 pixel_corner(const float* cam, uint32_t gx, uint32_t gy)
 
 static uint32_t isqrt_u32(uint32_t n) { uint32_t r = (uint32_t)sqrt((double)n); while (r * r > n) --r; while ((r + 1) * (r + 1) <= n) ++r; return r; }
 
-static ray camera_ray(const float* cam, const orc_params* p, uint32_t seed_k, uint32_t gx, uint32_t gy, uint32_t sample, uint32_t* key_out)
+static ray camera_ray(const float* cam, const orc_params* p, uint32_t seed_k, uint32_t gx, uint32_t gy, uint32_t sample, pathrng* g)
 {
     float step = cam[19];
     v3 pos = cam3(cam, 0), up = cam3(cam, 12), right = cam3(cam, 16);
     v3 pc = pixel_corner(cam, gx, gy);
-    uint32_t key = orc_hash32(orc_hash32(seed_k ^ (gy * p->width + gx)) ^ sample);
-    *key_out = key;
+    g->key = orc_hash32(orc_hash32(seed_k ^ (gy * p->width + gx)) ^ sample);
+    g->glsl = p->rng == ORC_RNG_GLSL;
+    if (g->glsl) orc_glsl_seed(p->seed, p->width, p->height, gx, gy, sample, g->s);
     v3 origin;
     if (p->sample_mode == ORC_SAMPLE_JITTER) {
         /* RayTracing.glsl:296 */
-        float s1 = step * orc_draw(key, DRAW_JITTER), s2 = step * orc_draw(key, DRAW_JITTER + 1);
+        float u1 = rdraw(g, DRAW_JITTER), u2 = rdraw(g, DRAW_JITTER + 1);     /* first draw goes with `right` */
+        float s1 = step * u1, s2 = step * u2;
         origin = madd(-s2, up, madd(s1, right, pc));
     } else {
         /* renderPixel<N>, rayTracer.h:92-101 */
@@ -594,7 +639,7 @@ static ray camera_ray(const float* cam, const orc_params* p, uint32_t seed_k, ui
 
 void orc_camera_ray(const float camera[21], const orc_params* p, uint32_t gx, uint32_t gy, uint32_t sample, float origin[3], float dir[3])
 {
-    uint32_t key;
+    pathrng key;
     orc_params q = *p;
     if (q.sample_mode != ORC_SAMPLE_JITTER && q.grid_n == 0) q.grid_n = isqrt_u32(q.first_sample + q.spp);
     ray r = camera_ray(camera, &q, seed_key(p->seed), gx, gy, sample, &key);
@@ -604,12 +649,12 @@ void orc_camera_ray(const float camera[21], const orc_params* p, uint32_t gx, ui
 
 static v3 path_color(tracer* T, uint32_t gx, uint32_t gy, uint32_t sample)
 {
-    uint32_t key;
+    pathrng key;
     ray r = camera_ray(T->cam, T->p, T->seed_k, gx, gy, sample, &key);
     T->st.samples++;
-    if (T->p->semantics == ORC_SEM_GLSL) return ray_color_glsl(T, r, (int)T->p->max_depth, key);
-    if (T->p->color_order == ORC_COLOR_FORWARD) return ray_color_cpu_forward(T, r, (int)T->p->max_depth, key);
-    return ray_color_cpu_recursive(T, r, (int)T->p->max_depth - 1, key, 0);
+    if (T->p->semantics == ORC_SEM_GLSL) return ray_color_glsl(T, r, (int)T->p->max_depth, &key);
+    if (T->p->color_order == ORC_COLOR_FORWARD) return ray_color_cpu_forward(T, r, (int)T->p->max_depth, &key);
+    return ray_color_cpu_recursive(T, r, (int)T->p->max_depth - 1, &key, 0);
 }
 
 /* uvec4(255 * color), RayTracing.glsl:301.  GLSL leaves negative and

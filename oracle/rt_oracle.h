@@ -32,6 +32,9 @@ typedef struct { float position[4]; float a[3]; float beta; float m1[4]; float m
 enum { ORC_SEM_CPU = 0, ORC_SEM_GLSL = 1 };
 enum { ORC_SAMPLE_JITTER = 0, ORC_SAMPLE_GRID = 1, ORC_SAMPLE_GRID_COMPAT = 2 };
 enum { ORC_FLAG_METAL_UNNORMALIZED = 1u };
+/* Which stream feeds the draws: the counter hash (one value per (seed, pixel, sample, draw
+ * index)), or the shader's own random() (RayTracing.glsl:8-9,44-51), consumed in program order. */
+enum { ORC_RNG_HASH = 0, ORC_RNG_GLSL = 1 };
 /* Order in which the colour of a path is multiplied together (RT_SEM_CPU):
  * AS_WRITTEN = the recursion of rayTracer.h:121, innermost product first;
  * FORWARD    = running throughput from the camera outwards (the order an
@@ -53,6 +56,7 @@ typedef struct {
     uint32_t unit_sampler;
     uint32_t shard_index, shard_count, band_rows;   /* rows with (y/band)%count==index */
     int32_t  threads;                               /* <=0: all cores                  */
+    uint32_t rng;                                   /* ORC_RNG_HASH / ORC_RNG_GLSL     */
 } orc_params;
 
 typedef struct {
@@ -87,6 +91,8 @@ void orc_convert(uint32_t* accum, float* image_rgba, uint32_t width, uint32_t he
 uint32_t orc_hash32(uint32_t x);
 uint32_t orc_path_key(uint64_t seed, uint32_t pixel_index, uint32_t sample);
 float    orc_draw(uint32_t key, uint32_t index);
+float    orc_glsl_random(float seed[3]);
+void     orc_glsl_seed(uint64_t seed, uint32_t width, uint32_t height, uint32_t gx, uint32_t gy, uint32_t sample, float out[3]);
 void     orc_sincos2pi(float u, float* c, float* s);
 void     orc_unit_vector(float u1, float u2, float out[3]);
 void     orc_hemisphere_glsl(const float n[3], float u1, float u2, float out[3]);

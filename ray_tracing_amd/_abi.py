@@ -16,6 +16,7 @@ RT_CAMERA_FLOATS = 21
 # enum rt_semantics / rt_sample_mode / rt_flags
 SEM_CPU, SEM_GLSL = 0, 1
 SAMPLE_JITTER, SAMPLE_GRID, SAMPLE_GRID_COMPAT = 0, 1, 2
+RNG_HASH, RNG_GLSL = 0, 1
 FLAG_METAL_UNNORMALIZED = 1
 MAT_LIGHT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DEBUG = 0, 1, 2, 3, 100
 SHAPE_CIRCLE, SHAPE_BOX, SHAPE_CUBE = 0, 1, 3
@@ -31,7 +32,8 @@ assert MATERIAL_DTYPE.itemsize == 32 and SHAPE_DTYPE.itemsize == 144 and TRIANGL
 
 class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("semantics", C.c_uint32),
-                ("sample_mode", C.c_uint32), ("flags", C.c_uint32), ("triangle_albedo", C.c_float * 3)]
+                ("sample_mode", C.c_uint32), ("flags", C.c_uint32), ("triangle_albedo", C.c_float * 3),
+                ("rng", C.c_uint32)]
 
 
 class Stats(C.Structure):

@@ -350,6 +350,7 @@ int rt_create(rt_ctx** out, const rt_config* cfg)
         c = *cfg;
     }
     if (c.semantics > RT_SEM_GLSL) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown semantics %u", c.semantics);
+    if (c.rng > RT_RNG_GLSL) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown rng %u", c.rng);
     if (c.sample_mode > RT_SAMPLE_GRID_COMPAT) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown sample_mode %u", c.sample_mode);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -516,6 +517,9 @@ static int fill_params(rt_ctx* ctx, rtd::TraceParams& P, uint32_t width, uint32_
     if (ctx->shard_count <= 1) { P.shard_index = 0; P.shard_count = 1; P.band_rows = height; }
     else { P.shard_index = ctx->shard_index; P.shard_count = ctx->shard_count; P.band_rows = ctx->band_rows; }
     P.owned_rows = owned_rows(ctx, height);
+    P.rng_mode = ctx->cfg.rng;
+    P.glsl_seed32 = (uint32_t)seed;
+    P.inv_w = 1.0f / (float)width; P.inv_h = 1.0f / (float)height;
     P.tiles_x = (P.width + rtd::TILE_W - 1) / rtd::TILE_W;
     P.tiles_y = (P.owned_rows + rtd::TILE_H - 1) / rtd::TILE_H;
     return RT_OK;

@@ -118,6 +118,25 @@ RT_DEV float draw(uint32_t key, uint32_t index)
 // Draws 0,1: sub-pixel jitter.  Bounce b: draws 2+4b .. 5+4b.
 RT_DEV uint32_t bounce_draw(uint32_t bounce) { return 2u + 4u * bounce; }
 
+RT_DEV void sincos2pi(float u, float& c_out, float& s_out);
+
+// random() of RayTracing.glsl:44-51, the shader's own stream, for contexts created with
+// RT_RNG_GLSL: the state is the vec3 `seed` of RayTracing.glsl:9; every draw adds (1.78, 3.1,
+// 50.78) to it and returns fract(sin(dot(seed, (12.9898, 78.233, 51.112))) * 43758.5453123).
+// The sine is taken of the angle reduced to one turn, with the polynomial used everywhere
+// here.  Draws are consumed in program order, so the state travels with the path.
+RT_DEV float glsl_random(V3& s)
+{
+    s = v3(s.x + 1.78f, s.y + 3.1f, s.z + 50.78f);
+    const float x = fma_(s.z, 51.112f, fma_(s.y, 78.233f, s.x * 12.9898f));
+    const float t = x * 0x1.45f306p-3f;                  // x / (2 pi)
+    const float u = t - __builtin_floorf(t);
+    float c, sn;
+    sincos2pi(u, c, sn);
+    const float v = sn * 43758.5453123f;
+    return v - __builtin_floorf(v);
+}
+
 // cos(2 pi u), sin(2 pi u), u in [0,1), without a quadrant case split: the half
 // angle h = pi*u - pi/2 lies in [-pi/2, pi/2), where one odd and one even Taylor
 // polynomial (Horner form) give sin h and cos h; then cos(2 pi u) = sin^2 h -
@@ -330,7 +349,8 @@ RT_DEV uint32_t quantise(float c)
 // SEM 1: rules of RayTracing.glsl:233-288.
 // GEO bit 0: the triangles did not fit into LDS and are read from the blob in
 // global memory; bit 1: the scene holds cubes of the CPU tracer (kept out of the
-// other instances, whose registers they would cost).  MODE 0: render.  MODE 1: render and count work.  MODE 2:
+// other instances, whose registers they would cost); bit 2: draws come from the
+// shader's own random() instead of the counter hash.  MODE 0: render.  MODE 1: render and count work.  MODE 2:
 // follow one sample, record hit and material ids, leave the accumulator alone.
 //
 // One loop iteration = one ray segment of every live lane: closest hit, then
@@ -350,7 +370,7 @@ void trace_kernel(const TraceParams P,
                   uint32_t* __restrict__ tile_cost)
 {
     constexpr bool STATS = MODE == 1, TRACE = MODE == 2;
-    constexpr bool TRI_GLOBAL = (GEO & 1) != 0, HAS_CUBE = SEM == 0 && (GEO & 2) != 0;
+    constexpr bool TRI_GLOBAL = (GEO & 1) != 0, HAS_CUBE = SEM == 0 && (GEO & 2) != 0, RNG_GLSL = (GEO & 4) != 0;
     extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < P.scene.lds_words; i += BLOCK) lds[i] = blob[i];
@@ -423,11 +443,30 @@ void trace_kernel(const TraceParams P,
         return org;
     };
 
+    // RayTracing.glsl:9 for sample `smp` of this pixel: frame = smp / 100, local invocation
+    // (smp % 10, smp / 10 % 10) of the pixel's 10 x 10 work group; `time` = (seed + frame) / 10000.
+    auto glsl_seed = [&](uint32_t smp) -> V3 {
+        const uint32_t frame = smp / 100u, lx = smp % 10u, ly = (smp / 10u) % 10u;
+        const float time = (float)(P.glsl_seed32 + frame) * 0.0001f;
+        return v3(time + (float)(10u * gx + lx) * P.inv_w, time + (float)(10u * gy + ly) * P.inv_h, time);
+    };
+    // The two draws that start sample `smp`: sub-pixel jitter, first draw with `right`.
+    auto start_draws = [&](uint32_t smp, uint32_t k, V3& state, float& a, float& b) {
+        if (RNG_GLSL) {
+            state = glsl_seed(smp);
+            a = b = 0.0f;
+            if (P.sample_mode == 0u) { a = glsl_random(state); b = glsl_random(state); }   // the grid modes draw nothing here
+        }
+        else { a = draw(k, 0u); b = draw(k, 1u); }
+    };
+    V3 gs = v3(0, 0, 0);               // the shader stream's state (RNG_GLSL)
     uint32_t key = 0, bounce = 0;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1), thr = v3(1, 1, 1);
     if (alive) {
         key = hash32(h1 ^ sample);
-        o = camera_origin(sample, draw(key, 0u), draw(key, 1u));
+        float j1, j2;
+        start_draws(sample, key, gs, j1, j2);
+        o = camera_origin(sample, j1, j2);
         d = normalize(o - cam_pos);
         if (STATS) ++n_samples;
     }
@@ -590,8 +629,20 @@ void trace_kernel(const TraceParams P,
             key = hash32(h1 ^ sample);
             if (STATS && alive) ++n_samples;
         }
-        const uint32_t di = ended ? 0u : bounce_draw(bounce);
-        const float u1 = draw(key, di), u2 = draw(key, di + 1u);
+        float u1, u2;
+        if (RNG_GLSL) {
+            // The shader draws only where its program does: two values for a new camera ray,
+            // two for a diffuse bounce (angle, then r: glsl:66-67), two for a fuzzy reflection
+            // of the CPU rules, none for a mirror.
+            if (ended) gs = glsl_seed(sample);
+            V3 g = gs;
+            u1 = glsl_random(g); u2 = glsl_random(g);
+            const bool uses = (ended && P.sample_mode == 0u) || (!ended && (diffuse || (SEM == 0 && metal && fuzz != 0.0f)));
+            gs = v3(uses ? g.x : gs.x, uses ? g.y : gs.y, uses ? g.z : gs.z);
+        } else {
+            const uint32_t di = ended ? 0u : bounce_draw(bounce);
+            u1 = draw(key, di); u2 = draw(key, di + 1u);
+        }
 
         if (ended) {
             o = camera_origin(sample, u1, u2);
@@ -627,7 +678,9 @@ void trace_kernel(const TraceParams P,
                     alive = sample < sample_end;
                     key = hash32(h1 ^ sample);
                     if (STATS && alive) ++n_samples;
-                    o = camera_origin(sample, draw(key, 0u), draw(key, 1u));
+                    float j1, j2;
+                    start_draws(sample, key, gs, j1, j2);
+                    o = camera_origin(sample, j1, j2);
                     v = o - cam_pos;
                     thr = v3(1, 1, 1);
                     bounce = 0;
@@ -848,11 +901,11 @@ hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams
     const dim3 grid(P.tiles_x * P.tiles_y);
     const float4* b = static_cast<const float4*>(blob);
     const size_t lds_bytes = (size_t)P.scene.lds_words * 16u;
-    const int geo = ((P.scene.n_tris != 0 && !P.scene.tri_in_lds) ? 1 : 0) | ((sem == 0 && P.scene.n_cube != 0) ? 2 : 0);
+    const int geo = ((P.scene.n_tris != 0 && !P.scene.tri_in_lds) ? 1 : 0) | ((sem == 0 && P.scene.n_cube != 0) ? 2 : 0) | (P.rng_mode ? 4 : 0);
 #define RT_CASE(S, G, M) if (sem == S && geo == G && mode == M) return launch_one<S, G, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm, tile_order, tile_cost)
 #define RT_CASES(S, G) RT_CASE(S, G, 0); RT_CASE(S, G, 1); RT_CASE(S, G, 2)
-    RT_CASES(0, 0); RT_CASES(0, 1); RT_CASES(0, 2); RT_CASES(0, 3);
-    RT_CASES(1, 0); RT_CASES(1, 1);
+    RT_CASES(0, 0); RT_CASES(0, 1); RT_CASES(0, 2); RT_CASES(0, 3); RT_CASES(0, 4); RT_CASES(0, 5); RT_CASES(0, 6); RT_CASES(0, 7);
+    RT_CASES(1, 0); RT_CASES(1, 1); RT_CASES(1, 4); RT_CASES(1, 5);
 #undef RT_CASES
 #undef RT_CASE
     return hipErrorInvalidValue;

@@ -204,7 +204,7 @@ class RayTracingComputeShader:
     """
 
     def __init__(self, camera, device=0, semantics=SEM_GLSL, sample_mode=SAMPLE_JITTER, flags=0,
-                 triangle_albedo=(1.0, 0.0, 0.0), samples_per_frame=100, max_depth=10, seed=1):
+                 triangle_albedo=(1.0, 0.0, 0.0), samples_per_frame=100, max_depth=10, seed=1, rng=0):
         self.camera = camera
         self.shapes = []
         self.triangles = []
@@ -215,7 +215,7 @@ class RayTracingComputeShader:
         self.frame = 0
         self.grid_n = 0
         cfg = _abi.Config(C.sizeof(_abi.Config), device, semantics, sample_mode, flags,
-                          (C.c_float * 3)(*triangle_albedo))
+                          (C.c_float * 3)(*triangle_albedo), rng)
         self._ctx = C.c_void_p()
         rc = lib.rt_create(C.byref(self._ctx), C.byref(cfg))
         if rc != 0:

@@ -31,6 +31,7 @@ class SceneConfig:
     sample_mode: int = _abi.SAMPLE_JITTER
     flags: int = 0
     triangle_albedo: tuple = (1.0, 0.0, 0.0)
+    rng: int = 0
     notes: dict = field(default_factory=dict)
 
 
@@ -182,7 +183,7 @@ def make_renderer(cfg, device=0):
     cam.data[:] = cfg.camera
     rt = host.RayTracingComputeShader(cam, device=device, semantics=cfg.semantics, sample_mode=cfg.sample_mode,
                                       flags=cfg.flags, triangle_albedo=cfg.triangle_albedo,
-                                      samples_per_frame=cfg.spp, max_depth=cfg.max_depth, seed=cfg.seed)
+                                      samples_per_frame=cfg.spp, max_depth=cfg.max_depth, seed=cfg.seed, rng=cfg.rng)
     rt.shapes = cfg.shapes
     rt.triangles = cfg.triangles
     rt.updateShapeBuffer()

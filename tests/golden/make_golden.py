@@ -41,6 +41,13 @@ def main():
     sincos = np.array([orc.sincos2pi(float(u)) for u in us], dtype=np.float32)
     unit = np.array([orc.unit_vector(float(us[i]), float(us[(7 * i + 3) % 64])) for i in range(64)], dtype=np.float32)
     hemi = np.array([orc.hemisphere_glsl((0.6, 0.0, 0.8), float(us[i]), float(us[(5 * i + 1) % 64])) for i in range(64)], dtype=np.float32)
+    import ctypes as C
+    glsl = []
+    for seed, w, h, gx, gy, smp in ((1, 64, 36, 0, 0, 0), (1000, 1920, 1080, 1919, 1079, 99), (77, 1080, 720, 500, 360, 250)):
+        st = (C.c_float * 3)()
+        orc.lib.orc_glsl_seed(seed, w, h, gx, gy, smp, st)
+        glsl.append(list(st) + [orc.lib.orc_glsl_random(st) for _ in range(13)])
+    np.savez_compressed(os.path.join(HERE, "shader_random.npz"), rows=np.array(glsl, dtype=np.float32))
     np.savez_compressed(os.path.join(HERE, "rng_and_samplers.npz"), keys=np.array(keys, dtype=np.uint64), path_keys=pkeys,
                         draws=draws, hashes=hashes, u=us, sincos=sincos, unit_vector=unit, hemisphere=hemi)
 

@@ -41,6 +41,17 @@ def test_rng_and_sampler_vectors(orc):
     np.testing.assert_array_equal(he.view(np.uint32), g["hemisphere"].view(np.uint32))
 
 
+def test_shader_random_vectors(orc):
+    import ctypes as C
+    rows = load("shader_random.npz")["rows"]
+    args = ((1, 64, 36, 0, 0, 0), (1000, 1920, 1080, 1919, 1079, 99), (77, 1080, 720, 500, 360, 250))
+    for want, a in zip(rows, args):
+        st = (C.c_float * 3)()
+        orc.lib.orc_glsl_seed(*a, st)
+        got = np.array(list(st) + [orc.lib.orc_glsl_random(st) for _ in range(13)], dtype=np.float32)
+        np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_host_side_fixtures(rta, orc):
     g = load("host_side.npz")
     cams = [(1920, 1080, (1, 1, 6)), (1080, 720, (1, 1, 6)), (512, 512, (1, 0, 6)), (3840, 2160, (1, 0, 6))]

@@ -16,7 +16,7 @@ COUNTERS = ("samples", "segments", "diffuse", "specular", "terminal",
 
 def oracle_params(orc, cfg, **kw):
     args = dict(seed=cfg.seed, semantics=cfg.semantics, sample_mode=cfg.sample_mode, flags=cfg.flags,
-                triangle_albedo=cfg.triangle_albedo)
+                triangle_albedo=cfg.triangle_albedo, rng=cfg.rng)
     args.update(kw)
     return orc.params(cfg.width, cfg.height, cfg.spp, cfg.max_depth, **args)
 
@@ -88,6 +88,24 @@ def test_cpu_tracer_scene_as_shipped(rta, orc):
     hit, mat = rt.traceDebug(160, 160, 11, cfg.seed, 0, grid_n=5)
     rt.close()
     assert (hit == 5).sum() > 50          # the cube (shape 5) is hit by some rays; its exact surface test passes only sometimes
+
+
+@pytest.mark.parametrize("name,kw", [("c3", dict(width=160, height=90, spp=8, max_depth=10)),
+                                     ("c4", dict(width=128, height=72, spp=8, max_depth=11)),
+                                     ("cpu_tracer", dict(width=96, height=96, spp=16, max_depth=11))])
+def test_shader_random_stream(rta, orc, name, kw):
+    """RT_RNG_GLSL: the draws come from random() of RayTracing.glsl:44-51 with the seed of :9, in program order."""
+    cfg = rta.scenes.CONFIGS[name](**kw)
+    cfg.rng = rta.RNG_GLSL
+    cfg.seed = 4321
+    check_config(rta, orc, cfg, trace_samples=(0, 7), grid_n=4 if name == "cpu_tracer" else 0)
+    # ... and it is a different stream from the counter hash
+    rt = rta.scenes.make_renderer(cfg); rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed)
+    a = rt.resolve(cfg.width, cfg.height); rt.close()
+    cfg.rng = rta.RNG_HASH
+    rt = rta.scenes.make_renderer(cfg); rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed)
+    b = rt.resolve(cfg.width, cfg.height); rt.close()
+    assert (a != b).any() and abs(a[..., :3].mean() - b[..., :3].mean()) < 0.25 * b[..., :3].mean() + 1e-3
 
 
 def test_metal_unnormalized_flag(rta, orc):

@@ -30,6 +30,35 @@ def test_hash_and_draws(orc):
     assert len({orc.lib.orc_path_key(1, p, s) for p in range(64) for s in range(64)}) == 4096
 
 
+def test_shader_random_stream(orc):
+    """random() of RayTracing.glsl:44-51 and its seed (:9), restated."""
+    import ctypes as C
+    f32 = np.float32
+    s = (C.c_float * 3)()
+    # sample 237 of pixel (12, 5) in a 64 x 36 frame: frame 2, local invocation (7, 3)
+    orc.lib.orc_glsl_seed(1000, 64, 36, 12, 5, 237, s)
+    time = f32(f32(1002) * f32(0.0001))
+    want = [f32(time + f32(f32(127) * f32(f32(1) / f32(64)))), f32(time + f32(f32(53) * f32(f32(1) / f32(36)))), time]
+    assert [f32(v) for v in s] == want
+    us = []
+    state = np.array(want, dtype=np.float64)
+    for n in range(200):
+        u = orc.lib.orc_glsl_random(s)
+        us.append(u)
+        assert 0.0 <= u <= 1.0
+        if n < 5:       # against the formula in double precision; the float sine of an angle in the thousands agrees to ~1e-3 turns
+            state += [1.78, 3.1, 50.78]
+            x = state @ [12.9898, 78.233, 51.112]
+            assert abs(float(s[0]) - state[0]) < 1e-5 and abs(float(s[2]) - state[2]) < 1e-4
+    us = np.array(us)
+    # fract(sin * 43758.5) keeps only ~8 fractional bits in binary32 — a property of the shader's generator itself
+    assert 0.35 < us.mean() < 0.65 and len(np.unique(us)) > 100
+    # different invocations give different streams
+    a, b = (C.c_float * 3)(), (C.c_float * 3)()
+    orc.lib.orc_glsl_seed(1000, 64, 36, 12, 5, 0, a); orc.lib.orc_glsl_seed(1000, 64, 36, 12, 5, 1, b)
+    assert orc.lib.orc_glsl_random(a) != orc.lib.orc_glsl_random(b)
+
+
 def test_sincos2pi(orc):
     # half-angle form: exact values are met to a few 1e-7, not bit for bit
     for u, want in ((0.0, (1.0, 0.0)), (0.25, (0.0, 1.0)), (0.5, (-1.0, 0.0)), (0.75, (0.0, -1.0)), (0.125, (2 ** -0.5, 2 ** -0.5))):
