@@ -41,9 +41,11 @@ def algorithmic_flops(st, executed=True):
             st["diffuse"] * F_DIFFUSE + st["specular"] * F_SPECULAR + st["terminal"] * F_TERMINAL)
 
 
-def cpu_baseline(cfg, target_seconds=12.0):
+def cpu_baseline(cfg, target_seconds=12.0, gpu_render=None):
     """The CPU oracle (a restatement of the reference's tracer; the reference itself cannot be built
-    here) timed on this host on a bounded sample of the same workload."""
+    here) timed on this host on a bounded sample of the same workload.  The frame it produces is
+    also compared, word for word, with the GPU's frame of the same samples (gpu_render(spp) ->
+    accumulator words): the PSNR of the headline metric."""
     from oracle import oracle as orc
     threads = max(1, min(16, os.cpu_count() or 1))
     p = orc.params(cfg.width, cfg.height, 1, cfg.max_depth, seed=cfg.seed, semantics=cfg.semantics,
@@ -56,12 +58,23 @@ def cpu_baseline(cfg, target_seconds=12.0):
     p.spp = spp
     t0 = time.perf_counter()
     for _ in range(frames):
-        orc.render(cfg.shapes, cfg.triangles, cfg.camera, p)
+        acc, _ = orc.render(cfg.shapes, cfg.triangles, cfg.camera, p)
     dt = time.perf_counter() - t0
     n = cfg.width * cfg.height * spp * frames
-    return {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": f"{frames} frame(s) of {cfg.width}x{cfg.height}, {spp} of {cfg.spp} spp, depth {cfg.max_depth}, "
-                      f"same scene and seed; {dt:.1f} s on {threads} threads"}
+    out = {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
+           "sample": f"{frames} frame(s) of {cfg.width}x{cfg.height}, {spp} of {cfg.spp} spp, depth {cfg.max_depth}, "
+                     f"same scene and seed; {dt:.1f} s on {threads} threads"}
+    if gpu_render is not None:
+        import numpy as np
+        got = gpu_render(spp)
+        differing = int((got != acc).sum())
+        a = orc.resolve(acc, spp, cfg.semantics, gamma_sqrt=(cfg.semantics == 0))[..., :3].astype(np.float64)
+        b = orc.resolve(got, spp, cfg.semantics, gamma_sqrt=(cfg.semantics == 0))[..., :3].astype(np.float64)
+        mse = float(((a - b) ** 2).mean())
+        out["image_vs_cpu"] = {"frame": f"{cfg.width}x{cfg.height}, {spp} spp", "differing_words": differing,
+                               "psnr_db": None if mse == 0.0 else round(10.0 * float(np.log10(max(a.max(), 1e-30) ** 2 / mse)), 2),
+                               "note": "psnr_db null = the two frames are bit-identical (infinite PSNR)"}
+    return out
 
 
 def main():
@@ -206,7 +219,13 @@ def main():
                          "note": "fp32 vector (VALU) bound: no dense contraction, no MFMA; HBM traffic is the framebuffer only"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(cfg)
+            def gpu_render(spp):
+                rt = rts[0]
+                rt.resetAccum()
+                rt.render(cfg.width, cfg.height, spp, cfg.max_depth, cfg.seed)
+                torch.cuda.synchronize()
+                return accums[0].cpu().numpy().view("uint32")
+            result["cpu_baseline"] = cpu_baseline(cfg, gpu_render=gpu_render)
         print(json.dumps(result), flush=True)
 
     for rt in rts:
