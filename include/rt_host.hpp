@@ -42,6 +42,10 @@ public:
         data[1] = fuzz;
     }
 };
+class Dielectric : public Material {         // extension, no counterpart in the reference: data[0] = index of refraction
+public:
+    explicit Dielectric(const Vector3f& color, float ior = 1.5f) : Material(RT_MAT_DIELECTRIC) { setColor(color); data[0] = ior; }
+};
 class DebugMaterial : public Material {      // shape.h:37-42
 public:
     explicit DebugMaterial(const Vector3f& color) : Material(RT_MAT_DEBUG) { setColor(color); }

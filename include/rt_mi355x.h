@@ -40,7 +40,8 @@ extern "C" {
 
 /* Material: src/gpu_version/shape.h:5-12.  type: 0 Light, 1 Lambertian,
  * 2 Metal, 100 Debug (shape.h:14-42); 3 Dielectric is an extension with no
- * counterpart in the reference.  data[0] is what the reference's Metal ctor
+ * counterpart in the reference (mirror with Schlick's probability, else refract at
+ * the surface; the sphere test has only the near root, so there is no exit event).  data[0] is what the reference's Metal ctor
  * stores ("refraction", never read by its shader; the Dielectric extension
  * reads it as the index of refraction); data[1] is the metal fuzz radius of
  * the CPU tracer (src/cpu_version/scene.h:71,78), 0 = perfect mirror. */

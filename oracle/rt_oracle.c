@@ -435,6 +435,25 @@ static v3 unit_vector(tracer* T, pathrng* g, uint32_t base)
     return V(u[0], u[1], u[2]);
 }
 
+/* Dielectric (material type 3; no counterpart in the reference, whose Metal::data[0] =
+ * "refraction" is never read): the ray is mirrored with Schlick's probability, refracted
+ * otherwise.  The sphere test knows only the near root, so a refracted ray leaves the
+ * sphere without a second event.  ior = material.data[0]. */
+static v3 glass_direction(v3 n, v3 d, float ior, float u1)
+{
+    float eta = 1.0f / ior;
+    float tt = (1.0f - ior) / (1.0f + ior);
+    float r0 = tt * tt;
+    float cosi = -dot(d, n);
+    float x = 1.0f - cosi, x2 = x * x;
+    float refl = fmaf(1.0f - r0, (x2 * x2) * x, r0);
+    v3 perp = vscale(madd(cosi, n, d), eta);
+    float par = -sqrtf(fabsf(1.0f - dot(perp, perp)));
+    v3 refr = madd(par, n, perp);
+    v3 mirr = madd(-(2.0f * dot(d, n)), n, d);
+    return (u1 < refl) ? mirr : refr;
+}
+
 /* Outcome of the surface interaction at one hit. */
 enum { EV_SCATTER = 0, EV_EMIT = 1 };
 
@@ -480,6 +499,15 @@ static int interact_cpu(tracer* T, int index, float t, ray* r, pathrng* key, int
         r->o = p;
         r->d = (T->p->flags & ORC_FLAG_METAL_UNNORMALIZED) ? dir : normalize(dir);
         *att = albedo;                                                 /* scene.h:79 */
+        return EV_SCATTER;
+    }
+    if (type == 3) {
+        float u1 = rdraw(key, DRAW_BOUNCE(bounce)), u2 = rdraw(key, DRAW_BOUNCE(bounce) + 1); (void)u2;
+        float ior = (index >= (int)T->n_shapes) ? 1.0f : T->shapes[index].mat.data[0];
+        v3 dir = glass_direction(n, r->d, ior, u1);
+        T->st.specular++;
+        r->o = p; r->d = normalize(dir);
+        *att = albedo;
         return EV_SCATTER;
     }
     if (type == 0) { *att = albedo; return EV_EMIT; }                  /* LightSource, scene.h:97-105 */
@@ -572,6 +600,15 @@ static v3 ray_color_glsl(tracer* T, ray r, int max_depth, pathrng* key)
             v3 n = shape_normal(s, r.o);
             float k = 2.0f * dot(r.d, n);
             r.d = normalize(madd(-k, n, r.d));
+            result = vmul(result, color);
+            T->st.specular++;
+            continue;
+        }
+        if (type == 3) {                                               /* dielectric extension */
+            r.o = madd(t, r.d, r.o);
+            v3 n = shape_normal(s, r.o);
+            float u1 = rdraw(key, DRAW_BOUNCE(bounce)), u2 = rdraw(key, DRAW_BOUNCE(bounce) + 1); (void)u2;
+            r.d = normalize(glass_direction(n, r.d, s->mat.data[0], u1));
             result = vmul(result, color);
             T->st.specular++;
             continue;

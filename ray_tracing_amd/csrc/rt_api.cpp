@@ -265,7 +265,7 @@ static int build_blob(rt_ctx* ctx)
     rtd::SceneLayout L{};
     L.n_shapes = n_shapes; L.n_sph_pad = (n_sph + 3u) & ~3u; L.n_box = n_box; L.n_cube = n_cube; L.n_tris = n_tris;
     L.rec_off = 0;
-    L.sph_off = L.rec_off + 3u * n_shapes;
+    L.sph_off = L.rec_off + 4u * n_shapes;
     L.sid_off = L.sph_off + L.n_sph_pad;
     L.box_off = L.sid_off + L.n_sph_pad / 4u;
     // Bounding-sphere tree over the triangles (rt_device.h).
@@ -302,7 +302,8 @@ static int build_blob(rt_ctx* ctx)
         const rt_shape& s = ctx->shapes[i];
         const float cx = s.transformation[12], cy = s.transformation[13], cz = s.transformation[14];
         const float scale = s.transformation[0];          // radius (shape.h:60) or side (RayTracing.glsl:139)
-        Word& r0 = blob[L.rec_off + 3u * i]; Word& r1 = blob[L.rec_off + 3u * i + 1u]; Word& r2 = blob[L.rec_off + 3u * i + 2u];
+        Word& r0 = blob[L.rec_off + 4u * i]; Word& r1 = blob[L.rec_off + 4u * i + 1u]; Word& r2 = blob[L.rec_off + 4u * i + 2u];
+        Word& r3 = blob[L.rec_off + 4u * i + 3u];
         r0.f[0] = cx; r0.f[1] = cy; r0.f[2] = cz; r0.f[3] = scale;
         float r = s.material.color[0], g = s.material.color[1], b = s.material.color[2];
         if (ctx->cfg.semantics == RT_SEM_CPU && s.material.type == RT_MAT_LAMBERTIAN) {
@@ -314,6 +315,12 @@ static int build_blob(rt_ctx* ctx)
         r2.f[0] = s.material.data[1];                     // fuzz
         r2.f[1] = s.material.data[0];                     // ior
         r2.f[2] = rcp_nr(scale);
+        if (s.material.type == RT_MAT_DIELECTRIC) {
+            L.has_glass = 1;
+            const float ior = s.material.data[0];
+            const float t = (1.0f - ior) / (1.0f + ior);
+            r3.f[0] = 1.0f / ior; r3.f[1] = t * t;
+        }
         if (s.type == RT_SHAPE_CIRCLE) {
             Word& w = blob[L.sph_off + is];
             w.f[0] = cx; w.f[1] = cy; w.f[2] = cz; w.f[3] = scale * scale;

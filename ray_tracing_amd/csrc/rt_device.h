@@ -12,11 +12,12 @@ namespace rtd {
 // (a mesh larger than the LDS budget) is read from the blob in global memory
 // with wave-uniform addresses.
 //
-//   rec  [3 * n_shapes]   per shape, by the shape's index in the uploaded array:
+//   rec  [4 * n_shapes]   per shape, by the shape's index in the uploaded array:
 //                           word 0: centre.xyz, scale (Circle: radius, Box: side)
 //                           word 1: colour.rgb (x 0.6 for Lambertian under CPU rules), tag
 //                                   tag = material type | shape type << 16
 //                           word 2: fuzz, ior, rcp_nr(scale), place in cub (uint32; cubes only)
+//                           word 3: dielectric: 1/ior, Schlick's r0 = ((1-ior)/(1+ior))^2
 //   sph  [n_sph_pad]      spheres in upload order: centre.xyz, radius^2; padded to a
 //                         multiple of 4 with NaN centres (never hit)
 //   sid  [n_sph_pad / 4]  the spheres' shape indices, four per word
@@ -44,6 +45,7 @@ struct SceneLayout {
     uint32_t total_words;                                   // whole blob
     uint32_t lds_words;                                     // prefix staged in LDS
     uint32_t tri_in_lds;                                    // 1 if inv and tri are part of that prefix
+    uint32_t has_glass;                                     // 1 if any shape has the dielectric material
 };
 
 // Everything one trace launch needs besides the blob; passed by value in the

@@ -348,8 +348,9 @@ RT_DEV uint32_t quantise(float c)
 // SEM 0: rules of src/cpu_version (rayTracer.h:110-132, scene.h:39-109).
 // SEM 1: rules of RayTracing.glsl:233-288.
 // GEO bit 0: the triangles did not fit into LDS and are read from the blob in
-// global memory; bit 1: the scene holds cubes of the CPU tracer (kept out of the
-// other instances, whose registers they would cost); bit 2: draws come from the
+// global memory; bit 1: the scene holds cubes of the CPU tracer or dielectric
+// materials (kept out of the other instances, whose registers and issue slots they
+// would cost: 12 % on the four-sphere scene); bit 2: draws come from the
 // shader's own random() instead of the counter hash.  MODE 0: render.  MODE 1: render and count work.  MODE 2:
 // follow one sample, record hit and material ids, leave the accumulator alone.
 //
@@ -370,7 +371,7 @@ void trace_kernel(const TraceParams P,
                   uint32_t* __restrict__ tile_cost)
 {
     constexpr bool STATS = MODE == 1, TRACE = MODE == 2;
-    constexpr bool TRI_GLOBAL = (GEO & 1) != 0, HAS_CUBE = SEM == 0 && (GEO & 2) != 0, RNG_GLSL = (GEO & 4) != 0;
+    constexpr bool TRI_GLOBAL = (GEO & 1) != 0, HAS_CUBE = SEM == 0 && (GEO & 2) != 0, HAS_GLASS = (GEO & 2) != 0, RNG_GLSL = (GEO & 4) != 0;
     extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < P.scene.lds_words; i += BLOCK) lds[i] = blob[i];
@@ -558,7 +559,7 @@ void trace_kernel(const TraceParams P,
         // ---- the surface
         uint32_t type = NONE;                  // nothing hit
         V3 n = v3(0, 0, 0), att = v3(0, 0, 0);
-        float fuzz = 0.0f;
+        float fuzz = 0.0f, glass_eta = 0.0f, glass_r0 = 0.0f;
         const float t_hit = __uint_as_float(best_key + Window<SEM>::tmin);
         const V3 p = madd(t_hit, d, o);                               // Ray::at / glsl:239
         if (best_id != NONE) {
@@ -568,18 +569,18 @@ void trace_kernel(const TraceParams P,
                 att = v3(P.tri_albedo[0], P.tri_albedo[1], P.tri_albedo[2]);
                 type = 1u;
             } else {
-                const float4 r0 = rec[3u * best_id], r1 = rec[3u * best_id + 1u];
+                const float4 r0 = rec[4u * best_id], r1 = rec[4u * best_id + 1u];
                 const uint32_t tag = __float_as_uint(r1.w);
                 const uint32_t stype = tag >> 16;
                 type = tag & 0xffffu;
                 att = xyz(r1);
                 if (stype == 0u) n = normalize(v3(p.x - r0.x, p.y - r0.y, p.z - r0.z));      // scene.h:130-132
-                else if (stype == 1u) n = box_normal(xyz(r0), rec[3u * best_id + 2u].z, p);
+                else if (stype == 1u) n = box_normal(xyz(r0), rec[4u * best_id + 2u].z, p);
                 else if (HAS_CUBE && stype == 3u) {
                     // rotation^T * normalAt(inPoint), scene.h:150-164,196: the row of the rotation that
                     // belongs to the largest |coordinate| of the point in the cube's frame (first of
                     // equals); the sign there is taken from an absolute value, so it is always +.
-                    const uint32_t ci = 4u * __float_as_uint(rec[3u * best_id + 2u].w);
+                    const uint32_t ci = 4u * __float_as_uint(rec[4u * best_id + 2u].w);
                     const float4 c0 = cub[ci], c1 = cub[ci + 1u], c2 = cub[ci + 2u];
                     V3 ip;
                     (void)hit_cube(c0, c1, c2, o, d, ip);
@@ -590,7 +591,8 @@ void trace_kernel(const TraceParams P,
                     n = z_gt ? xyz(c2) : (y_gt ? xyz(c1) : xyz(c0));
                 }
                 else n = v3(1.0f, 1.0f, 1.0f);                        // glsl:203
-                if (SEM == 0 && type == 2u) fuzz = rec[3u * best_id + 2u].x;
+                if (SEM == 0 && type == 2u) fuzz = rec[4u * best_id + 2u].x;
+                if (HAS_GLASS && type == 3u) { const float4 r3 = rec[4u * best_id + 3u]; glass_eta = r3.x; glass_r0 = r3.y; }
             }
         }
         if (TRACE) {
@@ -604,12 +606,12 @@ void trace_kernel(const TraceParams P,
         bool raw_dir = false;                                         // new direction is used as it is
         V3 color = v3(0, 0, 0);                                       // what the path returns if it ends here
         V3 v = v3(0, 0, 1);                                           // new direction before normalisation
-        const bool diffuse = type == 1u, metal = type == 2u;
-        if (STATS) { n_diffuse += diffuse ? 1u : 0u; n_specular += metal ? 1u : 0u; }
+        const bool diffuse = type == 1u, metal = type == 2u, glass = HAS_GLASS && type == 3u;
+        if (STATS) { n_diffuse += diffuse ? 1u : 0u; n_specular += (metal || glass) ? 1u : 0u; }
         if (type == 0u) color = thr * att;                            // LightSource::emit / glsl:278-280
         else if (type == 100u) color = (SEM == 0) ? thr * n : n;      // glsl:248-252
-        else if (!diffuse && !metal && type != NONE) color = (SEM == 0) ? v3(0, 0, 0) : thr;   // glsl:253,282-284
-        else if ((diffuse || metal) && !last) ended = false;
+        else if (!diffuse && !metal && !glass && type != NONE) color = (SEM == 0) ? v3(0, 0, 0) : thr;   // glsl:253,282-284
+        else if ((diffuse || metal || glass) && !last) ended = false;
 
         // Two draws per lane: the bounce's pair, or — for a lane that starts a
         // sample — the jitter pair of the new sample.
@@ -637,7 +639,7 @@ void trace_kernel(const TraceParams P,
             if (ended) gs = glsl_seed(sample);
             V3 g = gs;
             u1 = glsl_random(g); u2 = glsl_random(g);
-            const bool uses = (ended && P.sample_mode == 0u) || (!ended && (diffuse || (SEM == 0 && metal && fuzz != 0.0f)));
+            const bool uses = (ended && P.sample_mode == 0u) || (!ended && (diffuse || glass || (SEM == 0 && metal && fuzz != 0.0f)));
             gs = v3(uses ? g.x : gs.x, uses ? g.y : gs.y, uses ? g.z : gs.z);
         } else {
             const uint32_t di = ended ? 0u : bounce_draw(bounce);
@@ -660,6 +662,19 @@ void trace_kernel(const TraceParams P,
                     v = hemisphere_glsl(n, u1, u2);                   // glsl:240,274
                     raw_dir = true;
                 }
+            } else if (glass) {
+                // Dielectric (no counterpart in the reference): at the surface the ray is mirrored with
+                // Schlick's probability and refracted otherwise; the sphere test knows only the near
+                // root, so a refracted ray leaves the sphere without a second event.
+                const float cosi = -dot(d, n);
+                const float x = 1.0f - cosi, x2 = x * x;
+                const float refl = fma_(1.0f - glass_r0, (x2 * x2) * x, glass_r0);
+                const V3 perp = madd(cosi, n, d) * glass_eta;
+                const float par = -sqrt_rn(__builtin_fabsf(1.0f - dot(perp, perp)));
+                const V3 refr = madd(par, n, perp);
+                const V3 mirr = madd(-(2.0f * dot(d, n)), n, d);
+                const bool mirror = u1 < refl;
+                v = v3(mirror ? mirr.x : refr.x, mirror ? mirr.y : refr.y, mirror ? mirr.z : refr.z);
             } else if (SEM == 0) {
                 // Metal::scatter, scene.h:73-81; reflect, utils.h:62-64
                 v = madd(-(2.0f * dot(n, d)), n, d);
@@ -901,11 +916,11 @@ hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams
     const dim3 grid(P.tiles_x * P.tiles_y);
     const float4* b = static_cast<const float4*>(blob);
     const size_t lds_bytes = (size_t)P.scene.lds_words * 16u;
-    const int geo = ((P.scene.n_tris != 0 && !P.scene.tri_in_lds) ? 1 : 0) | ((sem == 0 && P.scene.n_cube != 0) ? 2 : 0) | (P.rng_mode ? 4 : 0);
+    const int geo = ((P.scene.n_tris != 0 && !P.scene.tri_in_lds) ? 1 : 0) | (((sem == 0 && P.scene.n_cube != 0) || P.scene.has_glass) ? 2 : 0) | (P.rng_mode ? 4 : 0);
 #define RT_CASE(S, G, M) if (sem == S && geo == G && mode == M) return launch_one<S, G, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm, tile_order, tile_cost)
 #define RT_CASES(S, G) RT_CASE(S, G, 0); RT_CASE(S, G, 1); RT_CASE(S, G, 2)
     RT_CASES(0, 0); RT_CASES(0, 1); RT_CASES(0, 2); RT_CASES(0, 3); RT_CASES(0, 4); RT_CASES(0, 5); RT_CASES(0, 6); RT_CASES(0, 7);
-    RT_CASES(1, 0); RT_CASES(1, 1); RT_CASES(1, 4); RT_CASES(1, 5);
+    RT_CASES(1, 0); RT_CASES(1, 1); RT_CASES(1, 2); RT_CASES(1, 3); RT_CASES(1, 4); RT_CASES(1, 5); RT_CASES(1, 6); RT_CASES(1, 7);
 #undef RT_CASES
 #undef RT_CASE
     return hipErrorInvalidValue;

@@ -48,6 +48,11 @@ class Metal(Material):                      # shape.h:28-34; fuzz: src/cpu_versi
         super().__init__(_abi.MAT_METAL, color, (refraction, fuzz, 0.0, 0.0))
 
 
+class Dielectric(Material):                 # extension: no counterpart in the reference
+    def __init__(self, color, ior=1.5):
+        super().__init__(_abi.MAT_DIELECTRIC, color, (ior, 0.0, 0.0, 0.0))
+
+
 class DebugMaterial(Material):              # shape.h:37-42
     def __init__(self, color):
         super().__init__(_abi.MAT_DEBUG, color)

@@ -139,9 +139,9 @@ def config4(width=3840, height=2160, spp=1024, max_depth=11):
 
 def config5(width=2048, height=2048, spp=64, max_depth=16):
     """Divergence stress (not in the reference): 64 spheres on a jittered 8x8
-    grid, materials round-robin diffuse / mirror / fuzzy metal / light."""
+    grid, materials round-robin diffuse / mirror / fuzzy metal / glass / light."""
     rng = np.random.RandomState(7)
-    L, M, Li = host.Lambertian, host.Metal, host.Light
+    L, M, Li, G = host.Lambertian, host.Metal, host.Light, host.Dielectric
     objs = [host.Circle((0, -1000.5, -6), 1000, L((0.5, 0.5, 0.5)))]
     k = 0
     for iz in range(8):
@@ -157,7 +157,7 @@ def config5(width=2048, height=2048, spp=64, max_depth=16):
             elif kind == 2:
                 m = M(col, fuzz=0.3)
             elif kind == 4:
-                m = M((0.95, 0.95, 0.95), fuzz=0.02)
+                m = G((0.95, 0.95, 0.95), ior=1.5)
             else:
                 m = Li(tuple(3.0 * c for c in col))
             objs.append(host.Circle(pos, 0.4, m))
