@@ -9,6 +9,7 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -118,16 +119,49 @@ struct Triangle { unsigned int idx0, idx1, idx2; };             // SimpleMesh.h:
 
 class SimpleMesh {
 public:
-    SimpleMesh() = default;
+    SimpleMesh() { if (rt_mesh_create(&mesh) != RT_OK) throw std::bad_alloc(); }           // SimpleMesh.h:42
     SimpleMesh(const SimpleMesh&) = delete;
     SimpleMesh& operator=(const SimpleMesh&) = delete;
+    SimpleMesh(SimpleMesh&& other) noexcept : mesh(other.mesh), vertices(std::move(other.vertices)), triangles(std::move(other.triangles)) { other.mesh = nullptr; }
     ~SimpleMesh() { rt_mesh_free(mesh); }
+
+    void clear() { rt_mesh_clear(mesh); refresh(); }            // SimpleMesh.h:47-50
+    unsigned int addVertex(const Vertex& v) { unsigned int id = rt_mesh_add_vertex(mesh, v.position, v.color); refresh(); return id; }   // :93-97
+    unsigned int addFace(unsigned int idx0, unsigned int idx1, unsigned int idx2)             // :99-104
+    {
+        unsigned int id = rt_mesh_add_face(mesh, idx0, idx1, idx2);
+        refresh();
+        return id;
+    }
+    void setColor(float r, float g, float b, float a) { rt_mesh_set_color(mesh, r, g, b, a); refresh(); }   // :87-91
+    bool writeMesh(const std::string& filename) const { return rt_mesh_write(mesh, filename.c_str()) == RT_OK; }   // :217-245
+    // pose1to2: 4x4 column-major (Eigen's default), applied to mesh1's positions.  SimpleMesh.h:251-288
+    static SimpleMesh joinMeshes(const SimpleMesh& mesh1, const SimpleMesh& mesh2, const float* pose1to2 = nullptr)
+    {
+        rt_mesh* joined = nullptr;
+        if (rt_mesh_join(&joined, mesh1.mesh, mesh2.mesh, pose1to2) != RT_OK) throw std::bad_alloc();
+        return SimpleMesh(joined);
+    }
+    static SimpleMesh sphere(const Vector3f& center, float scale = 1.f, const std::array<float, 4>& color = { 0, 0, 1, 1 })   // :293-317
+    {
+        rt_mesh* m = nullptr;
+        if (rt_mesh_sphere(&m, center.data(), scale, color.data()) != RT_OK) throw std::bad_alloc();
+        return SimpleMesh(m);
+    }
+    // rgb per face, the mean of its vertex colours: what rt_upload_triangle_colors takes.
+    std::vector<float> triangleColors() const
+    {
+        std::vector<float> rgb(3 * triangles.size());
+        rt_mesh_triangle_colors(mesh, rgb.data());
+        return rgb;
+    }
 
     bool loadMesh(const std::string& filename)                  // SimpleMesh.h:145-215
     {
+        rt_mesh* loaded = nullptr;
+        if (rt_mesh_load(&loaded, filename.c_str()) != RT_OK) { clear(); return false; }   // :147-148 clear first
         rt_mesh_free(mesh);
-        mesh = nullptr;
-        if (rt_mesh_load(&mesh, filename.c_str()) != RT_OK) return false;
+        mesh = loaded;
         refresh();
         return true;
     }
@@ -154,6 +188,7 @@ public:
     }
 
 private:
+    explicit SimpleMesh(rt_mesh* adopted) : mesh(adopted) { refresh(); }
     void refresh()
     {
         const uint32_t nv = rt_mesh_vertex_count(mesh), nt = rt_mesh_triangle_count(mesh);
@@ -206,6 +241,7 @@ public:
     {
         check(rt_upload_shapes(ctx, shapes.data(), (uint32_t)shapes.size()));
         check(rt_upload_triangles(ctx, triangles.data(), (uint32_t)triangles.size()));
+        if (!triangleColors.empty()) check(rt_upload_triangle_colors(ctx, triangleColors.data(), (uint32_t)(triangleColors.size() / 3)));
     }
     // The converter dispatch of src/main.cpp:147-149 (PixelConversion.glsl:12-28).
     void convert(unsigned int n_samples) { check(rt_convert(ctx, n_samples)); }
@@ -218,6 +254,7 @@ public:
 
     std::vector<Shape> shapes;                  // :59
     std::vector<SimpleTriangle> triangles;      // :60
+    std::vector<float> triangleColors;          // empty, or rgb per triangle (in place of RayTracing.glsl:275's red)
     unsigned int samplesPerFrame = 100;         // RayTracing.glsl:2,6
     unsigned int maxDepth = 10;                 // RayTracing.glsl:300
     uint64_t seed = 1;                          // stands in for the `time` uniform, main.cpp:139-141

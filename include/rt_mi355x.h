@@ -99,7 +99,11 @@ enum rt_flags {
     /* scene.h:78 leaves the fuzzed metal direction un-normalised although
      * Sphere::hit assumes a unit direction; by default it is normalised.
      * With this flag it is left as the reference leaves it. */
-    RT_FLAG_METAL_UNNORMALIZED = 1u << 0
+    RT_FLAG_METAL_UNNORMALIZED = 1u << 0,
+    /* Box::Box stores three sides on the diagonal of `transformation` (shape.h:67), but the
+     * shader reads only transformation[0][0] for all axes (RayTracing.glsl:139,159), so every
+     * Box is a cube there — the default here too.  With this flag a Box has its three sides. */
+    RT_FLAG_BOX_SIDES          = 1u << 1
 };
 
 /* Which stream feeds the random draws. */
@@ -180,6 +184,13 @@ int rt_set_stream(rt_ctx* ctx, void* hip_stream);
  * library copies and repacks them before returning.  n = 0 clears. */
 int rt_upload_shapes(rt_ctx* ctx, const rt_shape* shapes, uint32_t n);
 int rt_upload_triangles(rt_ctx* ctx, const rt_triangle* triangles, uint32_t n);
+
+/* One albedo per uploaded triangle (n x rgb), in place of the single colour the shader
+ * hard-codes (RayTracing.glsl:275; rt_config.triangle_albedo) — e.g. the vertex colours a
+ * COFF file carries (SimpleMesh.h:170-183), which the reference parses and then ignores;
+ * see rt_mesh_triangle_colors.  n must equal the number of uploaded triangles; n = 0 returns
+ * to the single colour, and so does every rt_upload_triangles. */
+int rt_upload_triangle_colors(rt_ctx* ctx, const float* rgb, uint32_t n);
 
 /* Replaces RayTracingComputeShader::updateCameraBuffer
  * (ray_tracing_compute_shader.h:34-37): 21 floats, Camera::data. */
@@ -321,6 +332,23 @@ void     rt_mesh_copy_vertices(const rt_mesh* mesh, float* positions_xyzw, float
 void     rt_mesh_copy_indices(const rt_mesh* mesh, uint32_t* indices);
 /* Writes rt_mesh_triangle_count() SimpleTriangles. */
 void     rt_mesh_to_triangles(const rt_mesh* mesh, rt_triangle* out);
+/* Writes rt_mesh_triangle_count() x rgb: the mean of each face's three vertex colours
+ * (Vertex::color, SimpleMesh.h:27), for rt_upload_triangle_colors.  No counterpart in the
+ * reference, whose shader colours every triangle red. */
+void     rt_mesh_triangle_colors(const rt_mesh* mesh, float* rgb);
+/* The rest of SimpleMesh: an empty mesh (:42), clear :47-50, addVertex :93-97, addFace
+ * :99-104 (both return the new element's index), setColor :87-91, writeMesh :217-245 (a COFF
+ * file; colours are written as int(colour), as there), joinMeshes :251-288 (pose1to2: 4x4
+ * column-major applied to mesh1's positions, NULL = identity), sphere :293-317 (the
+ * 12-vertex, 20-face icosahedron). */
+int      rt_mesh_create(rt_mesh** out);
+void     rt_mesh_clear(rt_mesh* mesh);
+uint32_t rt_mesh_add_vertex(rt_mesh* mesh, const float position_xyzw[4], const float color_rgba[4]);
+uint32_t rt_mesh_add_face(rt_mesh* mesh, uint32_t idx0, uint32_t idx1, uint32_t idx2);
+void     rt_mesh_set_color(rt_mesh* mesh, float r, float g, float b, float a);
+int      rt_mesh_write(const rt_mesh* mesh, const char* off_path);
+int      rt_mesh_join(rt_mesh** out, const rt_mesh* mesh1, const rt_mesh* mesh2, const float pose1to2_colmajor[16]);
+int      rt_mesh_sphere(rt_mesh** out, const float center[3], float scale, const float color_rgba[4]);
 
 /* Library / device facts for reports. */
 int rt_device_info(int device, char* name, size_t name_len, int* compute_units,

@@ -17,6 +17,7 @@ SAMPLE_JITTER, SAMPLE_GRID, SAMPLE_GRID_COMPAT = 0, 1, 2
 COLOR_AS_WRITTEN, COLOR_FORWARD = 0, 1
 UNIT_DIRECT, UNIT_GAUSS = 0, 1
 RNG_HASH, RNG_GLSL = 0, 1
+FLAG_METAL_UNNORMALIZED, FLAG_BOX_SIDES = 1, 2
 
 
 class Params(C.Structure):
@@ -25,7 +26,7 @@ class Params(C.Structure):
                 ("semantics", C.c_uint32), ("sample_mode", C.c_uint32), ("flags", C.c_uint32),
                 ("triangle_albedo", C.c_float * 3), ("color_order", C.c_uint32), ("unit_sampler", C.c_uint32),
                 ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("band_rows", C.c_uint32),
-                ("threads", C.c_int32), ("rng", C.c_uint32)]
+                ("threads", C.c_int32), ("rng", C.c_uint32), ("triangle_colors", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -65,6 +66,8 @@ def _load():
     lib.orc_hit_box.restype = C.c_float; lib.orc_hit_box.argtypes = [fp, C.c_float, fp, fp]
     lib.orc_hit_triangle.restype = C.c_float; lib.orc_hit_triangle.argtypes = [vp, fp, fp]
     lib.orc_box_normal.restype = None; lib.orc_box_normal.argtypes = [fp, C.c_float, fp, fp]
+    lib.orc_hit_box3.restype = C.c_float; lib.orc_hit_box3.argtypes = [fp, fp, fp, fp]
+    lib.orc_box_normal3.restype = None; lib.orc_box_normal3.argtypes = [fp, fp, fp, fp]
     lib.orc_hit_cube.restype = C.c_int; lib.orc_hit_cube.argtypes = [fp, fp, fp, fp, fp]
     lib.orc_cube_normal.restype = None; lib.orc_cube_normal.argtypes = [fp, fp, fp]
     lib.orc_camera_ray.restype = None; lib.orc_camera_ray.argtypes = [fp, C.POINTER(Params), u32, u32, u32, fp, fp]
@@ -88,9 +91,14 @@ def _fp(a):
 
 def params(width, height, spp, max_depth, seed=1, semantics=SEM_CPU, sample_mode=SAMPLE_JITTER, flags=0,
            first_sample=0, grid_n=0, triangle_albedo=(1.0, 0.0, 0.0), color_order=COLOR_FORWARD,
-           unit_sampler=UNIT_DIRECT, shard=(0, 1, 16), threads=0, rng=RNG_HASH):
-    return Params(width, height, spp, first_sample, max_depth, grid_n, seed, semantics, sample_mode, flags,
-                  (C.c_float * 3)(*triangle_albedo), color_order, unit_sampler, shard[0], shard[1], shard[2], threads, rng)
+           unit_sampler=UNIT_DIRECT, shard=(0, 1, 16), threads=0, rng=RNG_HASH, triangle_colors=None):
+    """triangle_colors: None, or float32 [n_triangles, 3] (kept alive by the returned object)."""
+    p = Params(width, height, spp, first_sample, max_depth, grid_n, seed, semantics, sample_mode, flags,
+               (C.c_float * 3)(*triangle_albedo), color_order, unit_sampler, shard[0], shard[1], shard[2], threads, rng, None)
+    if triangle_colors is not None and len(triangle_colors):
+        p._colors = np.ascontiguousarray(triangle_colors, dtype=np.float32).reshape(-1, 3)
+        p.triangle_colors = p._colors.ctypes.data
+    return p
 
 
 def render(shapes, triangles, camera, p, accum=None):
@@ -155,6 +163,16 @@ def hit_sphere(center, radius, o, d):
 
 def hit_box(center, scale, o, d):
     return lib.orc_hit_box(_f(*center), scale, _f(*o), _f(*d))
+
+
+def hit_box3(center, sides, o, d):
+    return lib.orc_hit_box3(_f(*center), _f(*sides), _f(*o), _f(*d))
+
+
+def box_normal3(center, sides, p):
+    o = _f(0, 0, 0)
+    lib.orc_box_normal3(_f(*center), _f(*sides), _f(*p), o)
+    return np.array(o[:], dtype=np.float32)
 
 
 def hit_triangle(tri_rec, o, d):

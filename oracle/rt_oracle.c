@@ -260,12 +260,14 @@ float orc_hit_sphere(const float cc[3], float radius, const float oo[3], const f
     return -b - sqrtf(disc);                                         /* :123 */
 }
 
-/* hitBox, RayTracing.glsl:138-156: a cube of side transformation[0][0]. */
-float orc_hit_box(const float cc[3], float scale, const float oo[3], const float dd[3])
+/* hitBox, RayTracing.glsl:138-156, with a side per axis.  The shader reads one side,
+ * transformation[0][0], for all three axes (:139), although Box::Box stores three
+ * (src/gpu_version/shape.h:67); orc_hit_box below is that case. */
+float orc_hit_box3(const float cc[3], const float sides[3], const float oo[3], const float dd[3])
 {
-    float inv = 1.0f / scale;                                        /* (1/scale)   :141 */
     float o[3], d[3], sg[3], t[3];
     for (int k = 0; k < 3; ++k) {
+        float inv = 1.0f / sides[k];                                 /* (1/scale)   :141 */
         o[k] = inv * (oo[k] - cc[k]);                                /* :141 */
         d[k] = inv * dd[k];                                          /* :142 */
         sg[k] = fsign(o[k]);                                         /* :144 */
@@ -282,18 +284,28 @@ float orc_hit_box(const float cc[3], float scale, const float oo[3], const float
     }
     return best;
 }
+float orc_hit_box(const float cc[3], float scale, const float oo[3], const float dd[3])
+{
+    const float sides[3] = { scale, scale, scale };
+    return orc_hit_box3(cc, sides, oo, dd);
+}
 
-/* boxNormalAt, RayTracing.glsl:158-163. */
-void orc_box_normal(const float cc[3], float scale, const float pp[3], float nn[3])
+/* boxNormalAt, RayTracing.glsl:158-163, with a side per axis (see orc_hit_box3). */
+void orc_box_normal3(const float cc[3], const float sides[3], const float pp[3], float nn[3])
 {
     float q[3];
     for (int k = 0; k < 3; ++k) {
-        float p = div_nr(pp[k] - cc[k], scale);                      /* :161 */
+        float p = div_nr(pp[k] - cc[k], sides[k]);                   /* :161 */
         float st = (fabsf(p) < 0.499f) ? 0.0f : 1.0f;                /* step(0.499,|p|) :162 */
         q[k] = st * fsign(p);
     }
     v3 n = normalize(V(q[0], q[1], q[2]));
     nn[0] = n.x; nn[1] = n.y; nn[2] = n.z;
+}
+void orc_box_normal(const float cc[3], float scale, const float pp[3], float nn[3])
+{
+    const float sides[3] = { scale, scale, scale };
+    orc_box_normal3(cc, sides, pp, nn);
 }
 
 /* Cube::hit, src/cpu_version/scene.h:185-204: the CPU tracer's unit cube.  m is the
@@ -368,12 +380,24 @@ typedef struct { v3 o, d; } ray;
 
 static inline v3 shape_center(const orc_shape* s) { return V(s->m[12], s->m[13], s->m[14]); }
 
+/* The sides of a Box: the shader's single side transformation[0][0] (RayTracing.glsl:139,159),
+ * or — ORC_FLAG_BOX_SIDES — the three sides Box::Box stores on the diagonal (shape.h:67). */
+static inline void box_sides(const orc_params* p, const orc_shape* s, float sides[3])
+{
+    const int own = (p->flags & ORC_FLAG_BOX_SIDES) != 0;
+    sides[0] = s->m[0]; sides[1] = own ? s->m[5] : s->m[0]; sides[2] = own ? s->m[10] : s->m[0];
+}
+
 static float hit_shape(tracer* T, const orc_shape* s, const ray* r)
 {
     float c[3] = { s->m[12], s->m[13], s->m[14] };
     float o[3] = { r->o.x, r->o.y, r->o.z }, d[3] = { r->d.x, r->d.y, r->d.z };
     if (s->type == 0) { T->st.sphere_tests++; return orc_hit_sphere(c, s->m[0], o, d); }
-    if (s->type == 1) { T->st.box_tests++;    return orc_hit_box(c, s->m[0], o, d); }
+    if (s->type == 1) {
+        float sides[3]; box_sides(T->p, s, sides);
+        T->st.box_tests++;
+        return orc_hit_box3(c, sides, o, d);
+    }
     if (s->type == 3 && T->p->semantics == ORC_SEM_CPU) {             /* the CPU tracer's Cube */
         float t, ip[3];
         return orc_hit_cube(s->m, o, d, &t, ip) ? t : INFINITY;
@@ -415,12 +439,13 @@ static int closest_hit(tracer* T, const ray* r, float* t_out)
     return index;
 }
 
-static v3 shape_normal(const orc_shape* s, v3 p)
+static v3 shape_normal(const orc_params* prm, const orc_shape* s, v3 p)
 {
     if (s->type == 0) return normalize(vsub(p, shape_center(s)));      /* scene.h:130-132, glsl:134-136 */
     if (s->type == 1) {
-        float c[3] = { s->m[12], s->m[13], s->m[14] }, pp[3] = { p.x, p.y, p.z }, n[3];
-        orc_box_normal(c, s->m[0], pp, n);
+        float c[3] = { s->m[12], s->m[13], s->m[14] }, pp[3] = { p.x, p.y, p.z }, n[3], sides[3];
+        box_sides(prm, s, sides);
+        orc_box_normal3(c, sides, pp, n);
         return V(n[0], n[1], n[2]);
     }
     return V(1.0f, 1.0f, 1.0f);                                       /* glsl:203 */
@@ -454,6 +479,14 @@ static v3 glass_direction(v3 n, v3 d, float ior, float u1)
     return (u1 < refl) ? mirr : refr;
 }
 
+/* Albedo of triangle i: one colour for all (RayTracing.glsl:275 hard-codes red), or the
+ * caller's colour per triangle. */
+static inline v3 triangle_color(const tracer* T, int i)
+{
+    const float* c = T->p->triangle_colors ? T->p->triangle_colors + 3 * (size_t)i : T->p->triangle_albedo;
+    return V(c[0], c[1], c[2]);
+}
+
 /* Outcome of the surface interaction at one hit. */
 enum { EV_SCATTER = 0, EV_EMIT = 1 };
 
@@ -468,7 +501,7 @@ static int interact_cpu(tracer* T, int index, float t, ray* r, pathrng* key, int
         const orc_triangle* tr = &T->tris[index - (int)T->n_shapes];
         v3 a = V(tr->a[0], tr->a[1], tr->a[2]);
         n = vscale(a, fsign(-dot(r->d, a)));                           /* glsl:165-167 */
-        albedo = V(T->p->triangle_albedo[0], T->p->triangle_albedo[1], T->p->triangle_albedo[2]);
+        albedo = triangle_color(T, index - (int)T->n_shapes);
         type = 1;
     } else {
         const orc_shape* s = &T->shapes[index];
@@ -477,7 +510,7 @@ static int interact_cpu(tracer* T, int index, float t, ray* r, pathrng* key, int
             orc_hit_cube(s->m, o, d, &tt, ip);
             orc_cube_normal(s->m, ip, nn);
             n = V(nn[0], nn[1], nn[2]);
-        } else n = shape_normal(s, p);
+        } else n = shape_normal(T->p, s, p);
         albedo = V(s->mat.color[0], s->mat.color[1], s->mat.color[2]);
         type = s->mat.type; fuzz = s->mat.data[1];
     }
@@ -574,7 +607,7 @@ static v3 ray_color_glsl(tracer* T, ray r, int max_depth, pathrng* key)
             float nn[3] = { n.x, n.y, n.z }, out[3];
             orc_hemisphere_glsl(nn, u1, u2, out);                      /* :274 */
             r.d = V(out[0], out[1], out[2]);
-            result = vmul(result, V(T->p->triangle_albedo[0], T->p->triangle_albedo[1], T->p->triangle_albedo[2])); /* :275 */
+            result = vmul(result, triangle_color(T, index - (int)T->n_shapes));   /* :275 */
             if (T->trace_mat) T->trace_mat[bounce] = 1;
             T->st.diffuse++;
             continue;
@@ -586,7 +619,7 @@ static v3 ray_color_glsl(tracer* T, ray r, int max_depth, pathrng* key)
         if (type == 0) { T->st.terminal++; return vmul(result, color); }  /* :278-280 (and :235-237) */
         if (type == 1) {                                               /* :238-242 */
             r.o = madd(t, r.d, r.o);
-            v3 n = shape_normal(s, r.o);
+            v3 n = shape_normal(T->p, s, r.o);
             float u1 = rdraw(key, DRAW_BOUNCE(bounce)), u2 = rdraw(key, DRAW_BOUNCE(bounce) + 1);
             float nn[3] = { n.x, n.y, n.z }, out[3];
             orc_hemisphere_glsl(nn, u1, u2, out);
@@ -597,7 +630,7 @@ static v3 ray_color_glsl(tracer* T, ray r, int max_depth, pathrng* key)
         }
         if (type == 2) {                                               /* :243-247, reflect :82-84 */
             r.o = madd(t, r.d, r.o);
-            v3 n = shape_normal(s, r.o);
+            v3 n = shape_normal(T->p, s, r.o);
             float k = 2.0f * dot(r.d, n);
             r.d = normalize(madd(-k, n, r.d));
             result = vmul(result, color);
@@ -606,7 +639,7 @@ static v3 ray_color_glsl(tracer* T, ray r, int max_depth, pathrng* key)
         }
         if (type == 3) {                                               /* dielectric extension */
             r.o = madd(t, r.d, r.o);
-            v3 n = shape_normal(s, r.o);
+            v3 n = shape_normal(T->p, s, r.o);
             float u1 = rdraw(key, DRAW_BOUNCE(bounce)), u2 = rdraw(key, DRAW_BOUNCE(bounce) + 1); (void)u2;
             r.d = normalize(glass_direction(n, r.d, s->mat.data[0], u1));
             result = vmul(result, color);
@@ -616,7 +649,7 @@ static v3 ray_color_glsl(tracer* T, ray r, int max_depth, pathrng* key)
         T->st.terminal++;
         if (type == 100) {                                             /* :248-252 */
             r.o = madd(t, r.d, r.o);
-            return shape_normal(s, r.o);
+            return shape_normal(T->p, s, r.o);
         }
         return result;                                                 /* :253, :282-284 */
     }

@@ -31,7 +31,8 @@ typedef struct { float position[4]; float a[3]; float beta; float m1[4]; float m
 
 enum { ORC_SEM_CPU = 0, ORC_SEM_GLSL = 1 };
 enum { ORC_SAMPLE_JITTER = 0, ORC_SAMPLE_GRID = 1, ORC_SAMPLE_GRID_COMPAT = 2 };
-enum { ORC_FLAG_METAL_UNNORMALIZED = 1u };
+/* BOX_SIDES: a Box has the three sides Box::Box stores (shape.h:67) instead of the one the shader reads. */
+enum { ORC_FLAG_METAL_UNNORMALIZED = 1u, ORC_FLAG_BOX_SIDES = 2u };
 /* Which stream feeds the draws: the counter hash (one value per (seed, pixel, sample, draw
  * index)), or the shader's own random() (RayTracing.glsl:8-9,44-51), consumed in program order. */
 enum { ORC_RNG_HASH = 0, ORC_RNG_GLSL = 1 };
@@ -57,6 +58,7 @@ typedef struct {
     uint32_t shard_index, shard_count, band_rows;   /* rows with (y/band)%count==index */
     int32_t  threads;                               /* <=0: all cores                  */
     uint32_t rng;                                   /* ORC_RNG_HASH / ORC_RNG_GLSL     */
+    const float* triangle_colors;                   /* NULL, or rgb per triangle (replaces triangle_albedo) */
 } orc_params;
 
 typedef struct {
@@ -98,6 +100,8 @@ void     orc_unit_vector(float u1, float u2, float out[3]);
 void     orc_hemisphere_glsl(const float n[3], float u1, float u2, float out[3]);
 float    orc_hit_sphere(const float center[3], float radius, const float o[3], const float d[3]);
 float    orc_hit_box(const float center[3], float scale, const float o[3], const float d[3]);
+float    orc_hit_box3(const float center[3], const float sides[3], const float o[3], const float d[3]);
+void     orc_box_normal3(const float center[3], const float sides[3], const float p[3], float n[3]);
 float    orc_hit_triangle(const orc_triangle* t, const float o[3], const float d[3]);
 void     orc_box_normal(const float center[3], float scale, const float p[3], float n[3]);
 int      orc_hit_cube(const float m[16], const float o[3], const float d[3], float* t, float in_point[3]);

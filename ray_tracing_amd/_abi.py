@@ -18,6 +18,7 @@ SEM_CPU, SEM_GLSL = 0, 1
 SAMPLE_JITTER, SAMPLE_GRID, SAMPLE_GRID_COMPAT = 0, 1, 2
 RNG_HASH, RNG_GLSL = 0, 1
 FLAG_METAL_UNNORMALIZED = 1
+FLAG_BOX_SIDES = 2
 MAT_LIGHT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DEBUG = 0, 1, 2, 3, 100
 SHAPE_CIRCLE, SHAPE_BOX, SHAPE_CUBE = 0, 1, 3
 
@@ -56,6 +57,7 @@ SIGNATURES = {
     "rt_set_stream": (_int, [_vp, _vp]),
     "rt_upload_shapes": (_int, [_vp, _vp, _u32]),
     "rt_upload_triangles": (_int, [_vp, _vp, _u32]),
+    "rt_upload_triangle_colors": (_int, [_vp, _vp, _u32]),
     "rt_set_camera": (_int, [_vp, _fp]),
     "rt_set_row_shard": (_int, [_vp, _u32, _u32, _u32]),
     "rt_bind_accum": (_int, [_vp, _vp, _u32, _u32]),
@@ -88,6 +90,15 @@ SIGNATURES = {
     "rt_mesh_copy_vertices": (None, [_vp, _vp, _vp]),
     "rt_mesh_copy_indices": (None, [_vp, _vp]),
     "rt_mesh_to_triangles": (None, [_vp, _vp]),
+    "rt_mesh_triangle_colors": (None, [_vp, _vp]),
+    "rt_mesh_create": (_int, [C.POINTER(_vp)]),
+    "rt_mesh_clear": (None, [_vp]),
+    "rt_mesh_add_vertex": (_u32, [_vp, _fp, _fp]),
+    "rt_mesh_add_face": (_u32, [_vp, _u32, _u32, _u32]),
+    "rt_mesh_set_color": (None, [_vp, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "rt_mesh_write": (_int, [_vp, C.c_char_p]),
+    "rt_mesh_join": (_int, [C.POINTER(_vp), _vp, _vp, _fp]),
+    "rt_mesh_sphere": (_int, [C.POINTER(_vp), _fp, C.c_float, _fp]),
     "rt_device_info": (_int, [_int, C.c_char_p, C.c_size_t, C.POINTER(_int), C.POINTER(_int)]),
 }
 

@@ -49,6 +49,7 @@ struct rt_ctx {
 
     std::vector<rt_shape> shapes;        // host copies of what was uploaded
     std::vector<rt_triangle> tris;
+    std::vector<float> tri_colors;       // empty, or rgb per triangle
     bool blob_dirty = true;              // the device blob does not reflect them yet
     void* d_blob = nullptr;              size_t blob_cap = 0;     // bytes
     rtd::SceneLayout layout{};
@@ -286,11 +287,14 @@ static int build_blob(rt_ctx* ctx)
     L.inv_off = off;
     L.tri_off = L.inv_off + (n_tris + 3u) / 4u;
     L.total_words = L.tri_off + 4u * n_tri_pad;
+    const bool colors = !ctx->tri_colors.empty() && ctx->tri_colors.size() == 3u * (size_t)n_tris;
     if ((size_t)L.inv_off * 16u > rtd::LDS_MAX_BYTES)
         return fail(ctx, RT_ERR_INVALID_ARG, "scene (%u shapes, %u triangles) needs more than the %u-byte LDS stage for shapes and bounds",
                     n_shapes, n_tris, rtd::LDS_MAX_BYTES);
     if ((size_t)L.total_words * 16u <= rtd::LDS_MAX_BYTES) { L.lds_words = L.total_words; L.tri_in_lds = 1; }
     else { L.lds_words = L.inv_off; L.tri_in_lds = 0; }
+    // Per-triangle albedo: read only at a hit, so it stays in global memory behind everything else.
+    if (colors) { L.tcol_off = L.total_words; L.total_words += n_tris; }
 
     std::vector<Word> blob(L.total_words ? L.total_words : 1u);
     memset(blob.data(), 0, blob.size() * sizeof(Word));
@@ -315,6 +319,10 @@ static int build_blob(rt_ctx* ctx)
         r2.f[0] = s.material.data[1];                     // fuzz
         r2.f[1] = s.material.data[0];                     // ior
         r2.f[2] = rcp_nr(scale);
+        // A Box's sides along y and z: the shader's single side, or its own (RT_FLAG_BOX_SIDES).
+        const bool own_sides = (ctx->cfg.flags & RT_FLAG_BOX_SIDES) != 0u;
+        const float side_y = own_sides ? s.transformation[5] : scale, side_z = own_sides ? s.transformation[10] : scale;
+        if (s.type == RT_SHAPE_BOX) { r3.f[2] = rcp_nr(side_y); r3.f[3] = rcp_nr(side_z); }
         if (s.material.type == RT_MAT_DIELECTRIC) {
             L.has_glass = 1;
             const float ior = s.material.data[0];
@@ -330,6 +338,7 @@ static int build_blob(rt_ctx* ctx)
             Word& w = blob[L.box_off + 2u * ib]; Word& w1 = blob[L.box_off + 2u * ib + 1u];
             w.f[0] = cx; w.f[1] = cy; w.f[2] = cz; w.f[3] = 1.0f / scale;
             as_u32(w1.f[0]) = i;
+            w1.f[1] = 1.0f / side_y; w1.f[2] = 1.0f / side_z;
             ++ib;
         } else if (s.type == RT_SHAPE_CUBE && ctx->cfg.semantics == RT_SEM_CPU) {
             Word* w = &blob[L.cub_off + 4u * ic];
@@ -344,6 +353,12 @@ static int build_blob(rt_ctx* ctx)
     }
     static_assert(sizeof(rt_triangle) == 4 * sizeof(Word), "a SimpleTriangle is four 16-byte words");
     if (n_tris) build_tree(ctx->tris, L, node_pad, n_tri_pad, blob);
+    if (colors) {
+        // Triangles scatter like Lambertians; under the CPU rules that is 0.6 * albedo (scene.h:56).
+        const float k = ctx->cfg.semantics == RT_SEM_CPU ? 0.6f : 1.0f;
+        for (uint32_t i = 0; i < n_tris; ++i)
+            for (int c = 0; c < 3; ++c) blob[L.tcol_off + i].f[c] = ctx->tri_colors[3u * i + c] * k;
+    }
 
     // The kernels may still be reading the old copy.
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -437,6 +452,18 @@ int rt_upload_triangles(rt_ctx* ctx, const rt_triangle* tris, uint32_t n)
     if (!ctx) return RT_ERR_INVALID_ARG;
     RT_REQUIRE(ctx, n == 0 || tris, "rt_upload_triangles: triangles is NULL");
     try { ctx->tris.assign(tris, tris + n); } catch (...) { return fail(ctx, RT_ERR_OUT_OF_MEMORY, "rt_upload_triangles: host allocation failed"); }
+    ctx->tri_colors.clear();
+    ctx->blob_dirty = true;
+    return build_blob(ctx);
+}
+
+int rt_upload_triangle_colors(rt_ctx* ctx, const float* rgb, uint32_t n)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_REQUIRE(ctx, n == 0 || rgb, "rt_upload_triangle_colors: rgb is NULL");
+    if (n != 0 && n != ctx->tris.size())
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_triangle_colors: %u colours for %zu uploaded triangles", n, ctx->tris.size());
+    try { ctx->tri_colors.assign(rgb, rgb + 3u * (size_t)n); } catch (...) { return fail(ctx, RT_ERR_OUT_OF_MEMORY, "rt_upload_triangle_colors: host allocation failed"); }
     ctx->blob_dirty = true;
     return build_blob(ctx);
 }

@@ -289,4 +289,133 @@ void rt_mesh_to_triangles(const rt_mesh* mesh, rt_triangle* out)
     }
 }
 
+
+// Mean of the three vertex colours of each face (Vertex::color, SimpleMesh.h:27).
+void rt_mesh_triangle_colors(const rt_mesh* mesh, float* rgb)
+{
+    if (!mesh || !rgb) return;
+    for (size_t t = 0; t < mesh->indices.size() / 3; ++t) {
+        const float* c0 = mesh->vertices[mesh->indices[3 * t]].color;
+        const float* c1 = mesh->vertices[mesh->indices[3 * t + 1]].color;
+        const float* c2 = mesh->vertices[mesh->indices[3 * t + 2]].color;
+        for (int k = 0; k < 3; ++k) rgb[3 * t + k] = ((c0[k] + c1[k]) + c2[k]) / 3.0f;
+    }
+}
+
+int rt_mesh_create(rt_mesh** out)                                // SimpleMesh(), SimpleMesh.h:42
+{
+    if (!out) return RT_ERR_INVALID_ARG;
+    *out = new (std::nothrow) rt_mesh();
+    return *out ? RT_OK : RT_ERR_OUT_OF_MEMORY;
+}
+
+void rt_mesh_clear(rt_mesh* mesh)                                // SimpleMesh.h:47-50
+{
+    if (!mesh) return;
+    mesh->vertices.clear();
+    mesh->indices.clear();
+}
+
+uint32_t rt_mesh_add_vertex(rt_mesh* mesh, const float position[4], const float color[4])   // SimpleMesh.h:93-97
+{
+    if (!mesh || !position) return 0xffffffffu;
+    rt_mesh::Vertex v{};
+    memcpy(v.position, position, 16);
+    if (color) memcpy(v.color, color, 16);
+    mesh->vertices.push_back(v);
+    return (uint32_t)mesh->vertices.size() - 1u;
+}
+
+uint32_t rt_mesh_add_face(rt_mesh* mesh, uint32_t idx0, uint32_t idx1, uint32_t idx2)      // SimpleMesh.h:99-104
+{
+    if (!mesh) return 0xffffffffu;
+    mesh->indices.push_back(idx0); mesh->indices.push_back(idx1); mesh->indices.push_back(idx2);
+    return (uint32_t)(mesh->indices.size() / 3) - 1u;
+}
+
+void rt_mesh_set_color(rt_mesh* mesh, float r, float g, float b, float a)                  // SimpleMesh.h:87-91
+{
+    if (!mesh) return;
+    for (auto& v : mesh->vertices) { v.color[0] = r; v.color[1] = g; v.color[2] = b; v.color[3] = a; }
+}
+
+// SimpleMesh::writeMesh, SimpleMesh.h:217-245.  Numbers are formatted as an ostream's default
+// does (%g); colours go out as int(colour), which after loadMesh's division by 255 is 0 or 1.
+int rt_mesh_write(const rt_mesh* mesh, const char* path)
+{
+    if (!mesh || !path) return RT_ERR_INVALID_ARG;
+    FILE* f = fopen(path, "w");
+    if (!f) return RT_ERR_IO;                                    // :220
+    fprintf(f, "COFF\n%zu %zu 0\n", mesh->vertices.size(), mesh->indices.size() / 3);   // :223-224
+    for (const auto& v : mesh->vertices) {
+        const bool finite = std::isfinite(v.position[0]) && std::isfinite(v.position[1]) && std::isfinite(v.position[2]) &&
+                            std::isfinite(v.position[3]);         // :229
+        if (finite)
+            fprintf(f, "%g %g %g %d %d %d %d\n", v.position[0], v.position[1], v.position[2],
+                    (int)v.color[0], (int)v.color[1], (int)v.color[2], (int)v.color[3]);   // :230-231
+        else
+            fprintf(f, "0.0 0.0 0.0 0 0 0 0\n");                 // :233
+    }
+    for (size_t t = 0; t < mesh->indices.size() / 3; ++t)
+        fprintf(f, "3 %u %u %u\n", mesh->indices[3 * t], mesh->indices[3 * t + 1], mesh->indices[3 * t + 2]);   // :238
+    const bool ok = !ferror(f);
+    return (fclose(f) == 0 && ok) ? RT_OK : RT_ERR_IO;
+}
+
+// SimpleMesh::joinMeshes, SimpleMesh.h:251-288.
+int rt_mesh_join(rt_mesh** out, const rt_mesh* mesh1, const rt_mesh* mesh2, const float pose[16])
+{
+    if (!out || !mesh1 || !mesh2) return RT_ERR_INVALID_ARG;
+    *out = nullptr;
+    rt_mesh* joined = new (std::nothrow) rt_mesh();
+    if (!joined) return RT_ERR_OUT_OF_MEMORY;
+    const uint32_t n1 = (uint32_t)mesh1->vertices.size();
+    joined->vertices.reserve(n1 + mesh2->vertices.size());
+    for (const auto& v1 : mesh1->vertices) {                     // :270-276
+        rt_mesh::Vertex v{};
+        if (pose) {
+            for (int i = 0; i < 4; ++i)
+                v.position[i] = ((pose[i] * v1.position[0] + pose[4 + i] * v1.position[1]) + pose[8 + i] * v1.position[2]) +
+                                pose[12 + i] * v1.position[3];
+        } else {
+            memcpy(v.position, v1.position, 16);
+        }
+        memcpy(v.color, v1.color, 16);
+        joined->vertices.push_back(v);
+    }
+    for (const auto& v2 : mesh2->vertices) joined->vertices.push_back(v2);                  // :277
+    joined->indices = mesh1->indices;                                                       // :280
+    for (uint32_t idx : mesh2->indices) joined->indices.push_back(idx + n1);                // :281-285
+    *out = joined;
+    return RT_OK;
+}
+
+// SimpleMesh::sphere, SimpleMesh.h:293-317: an icosahedron; vertex and face order as there, so
+// that triangle indices agree.
+int rt_mesh_sphere(rt_mesh** out, const float center[3], float scale, const float color[4])
+{
+    if (!out || !center) return RT_ERR_INVALID_ARG;
+    *out = nullptr;
+    rt_mesh* mesh = new (std::nothrow) rt_mesh();
+    if (!mesh) return RT_ERR_OUT_OF_MEMORY;
+    const double X = 0.525731, Z = 0.850651;                     // :298-299
+    const double verts[12][3] = { { -X, 0, Z }, { X, 0, Z }, { -X, 0, -Z }, { X, 0, -Z }, { 0, Z, X }, { 0, Z, -X },
+                                  { 0, -Z, X }, { 0, -Z, -X }, { Z, X, 0 }, { -Z, X, 0 }, { Z, -X, 0 }, { -Z, -X, 0 } };
+    const uint32_t faces[20][3] = { { 0, 4, 1 }, { 0, 9, 4 }, { 9, 5, 4 }, { 4, 5, 8 }, { 4, 8, 1 }, { 8, 10, 1 }, { 8, 3, 10 },
+                                    { 5, 3, 8 }, { 5, 2, 3 }, { 2, 7, 3 }, { 7, 10, 3 }, { 7, 6, 10 }, { 7, 11, 6 }, { 11, 0, 6 },
+                                    { 0, 1, 6 }, { 6, 1, 10 }, { 9, 0, 11 }, { 9, 11, 2 }, { 9, 2, 5 }, { 7, 2, 11 } };   // :300-301
+    const float default_color[4] = { 0, 0, 1, 1 };               // :293
+    const float* col = color ? color : default_color;
+    for (int i = 0; i < 12; ++i) {                               // :304-309
+        rt_mesh::Vertex v{};
+        for (int k = 0; k < 3; ++k) v.position[k] = center[k] + scale * (float)verts[i][k];
+        v.position[3] = 1.0f + scale * 0.0f;
+        memcpy(v.color, col, 16);
+        mesh->vertices.push_back(v);
+    }
+    for (int i = 0; i < 20; ++i) for (int k = 0; k < 3; ++k) mesh->indices.push_back(faces[i][k]);   // :312-314
+    *out = mesh;
+    return RT_OK;
+}
+
 }  // extern "C"

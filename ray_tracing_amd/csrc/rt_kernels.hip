@@ -244,12 +244,13 @@ RT_DEV void test_sphere(float4 s, uint32_t shape_id, V3 o, V3 d, Best& best)
     take_if_closer(best, __float_as_uint(t) - Window<SEM>::tmin, shape_id);
 }
 
-// hitBox, RayTracing.glsl:138-156.  bx = centre.xyz, 1/side.
-RT_DEV float hit_box(float4 bx, V3 o, V3 d)
+// hitBox, RayTracing.glsl:138-156.  bx = centre.xyz, 1/side along x; iy, iz = 1/side along
+// y and z (the shader has one side for all three, :139).
+RT_DEV float hit_box(float4 bx, float iy, float iz, V3 o, V3 d)
 {
-    const float inv = bx.w;
-    V3 ob = v3(inv * (o.x - bx.x), inv * (o.y - bx.y), inv * (o.z - bx.z));
-    V3 db = v3(inv * d.x, inv * d.y, inv * d.z);
+    const float ix = bx.w;
+    V3 ob = v3(ix * (o.x - bx.x), iy * (o.y - bx.y), iz * (o.z - bx.z));
+    V3 db = v3(ix * d.x, iy * d.y, iz * d.z);
     V3 sg = v3(sign_(ob.x), sign_(ob.y), sign_(ob.z));
     float t[3];
     t[0] = (0.5f - ob.x * sg.x) * rcp_nr(sg.x * db.x);
@@ -267,10 +268,10 @@ RT_DEV float hit_box(float4 bx, V3 o, V3 d)
     return best;
 }
 
-// boxNormalAt, RayTracing.glsl:158-163.  c = centre, rs = rcp_nr(side).
-RT_DEV V3 box_normal(V3 c, float rs, V3 p)
+// boxNormalAt, RayTracing.glsl:158-163.  c = centre, rx, ry, rz = rcp_nr(side) per axis.
+RT_DEV V3 box_normal(V3 c, float rx, float ry, float rz, V3 p)
 {
-    float qx = (p.x - c.x) * rs, qy = (p.y - c.y) * rs, qz = (p.z - c.z) * rs;
+    float qx = (p.x - c.x) * rx, qy = (p.y - c.y) * ry, qz = (p.z - c.z) * rz;
     V3 n = v3(((__builtin_fabsf(qx) < 0.499f) ? 0.0f : 1.0f) * sign_(qx),
               ((__builtin_fabsf(qy) < 0.499f) ? 0.0f : 1.0f) * sign_(qy),
               ((__builtin_fabsf(qz) < 0.499f) ? 0.0f : 1.0f) * sign_(qz));
@@ -348,8 +349,8 @@ RT_DEV uint32_t quantise(float c)
 // SEM 0: rules of src/cpu_version (rayTracer.h:110-132, scene.h:39-109).
 // SEM 1: rules of RayTracing.glsl:233-288.
 // GEO bit 0: the triangles did not fit into LDS and are read from the blob in
-// global memory; bit 1: the scene holds cubes of the CPU tracer or dielectric
-// materials (kept out of the other instances, whose registers and issue slots they
+// global memory; bit 1: the scene holds cubes of the CPU tracer, dielectric
+// materials or a colour per triangle (kept out of the other instances, whose registers and issue slots they
 // would cost: 12 % on the four-sphere scene); bit 2: draws come from the
 // shader's own random() instead of the counter hash.  MODE 0: render.  MODE 1: render and count work.  MODE 2:
 // follow one sample, record hit and material ids, leave the accumulator alone.
@@ -371,7 +372,7 @@ void trace_kernel(const TraceParams P,
                   uint32_t* __restrict__ tile_cost)
 {
     constexpr bool STATS = MODE == 1, TRACE = MODE == 2;
-    constexpr bool TRI_GLOBAL = (GEO & 1) != 0, HAS_CUBE = SEM == 0 && (GEO & 2) != 0, HAS_GLASS = (GEO & 2) != 0, RNG_GLSL = (GEO & 4) != 0;
+    constexpr bool TRI_GLOBAL = (GEO & 1) != 0, HAS_CUBE = SEM == 0 && (GEO & 2) != 0, HAS_GLASS = (GEO & 2) != 0, HAS_TCOL = (GEO & 2) != 0, RNG_GLSL = (GEO & 4) != 0;
     extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < P.scene.lds_words; i += BLOCK) lds[i] = blob[i];
@@ -511,8 +512,8 @@ void trace_kernel(const TraceParams P,
         }
         for (uint32_t i = 0; i < n_box; ++i) {
             const float4 bx = box[2u * i];
-            const uint32_t bid = __float_as_uint(box[2u * i + 1u].x);
-            take_if_closer(best, __float_as_uint(hit_box(bx, o, d)) - Window<SEM>::tmin, bid);
+            const float4 bx1 = box[2u * i + 1u];
+            take_if_closer(best, __float_as_uint(hit_box(bx, bx1.y, bx1.z, o, d)) - Window<SEM>::tmin, __float_as_uint(bx1.x));
         }
         if (HAS_CUBE) {
             for (uint32_t i = 0; i < L.n_cube; ++i) {
@@ -567,6 +568,7 @@ void trace_kernel(const TraceParams P,
                 V3 a = xyz(tri[4u * slot_of[best_id - n_shapes] + 1u]);
                 n = a * sign_(-dot(d, a));                            // glsl:165-167,272
                 att = v3(P.tri_albedo[0], P.tri_albedo[1], P.tri_albedo[2]);
+                if (HAS_TCOL && L.tcol_off != 0u) att = xyz(blob[L.tcol_off + (best_id - n_shapes)]);
                 type = 1u;
             } else {
                 const float4 r0 = rec[4u * best_id], r1 = rec[4u * best_id + 1u];
@@ -575,7 +577,7 @@ void trace_kernel(const TraceParams P,
                 type = tag & 0xffffu;
                 att = xyz(r1);
                 if (stype == 0u) n = normalize(v3(p.x - r0.x, p.y - r0.y, p.z - r0.z));      // scene.h:130-132
-                else if (stype == 1u) n = box_normal(xyz(r0), rec[4u * best_id + 2u].z, p);
+                else if (stype == 1u) { const float4 r3 = rec[4u * best_id + 3u]; n = box_normal(xyz(r0), rec[4u * best_id + 2u].z, r3.z, r3.w, p); }
                 else if (HAS_CUBE && stype == 3u) {
                     // rotation^T * normalAt(inPoint), scene.h:150-164,196: the row of the rotation that
                     // belongs to the largest |coordinate| of the point in the cube's frame (first of
@@ -916,7 +918,7 @@ hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams
     const dim3 grid(P.tiles_x * P.tiles_y);
     const float4* b = static_cast<const float4*>(blob);
     const size_t lds_bytes = (size_t)P.scene.lds_words * 16u;
-    const int geo = ((P.scene.n_tris != 0 && !P.scene.tri_in_lds) ? 1 : 0) | (((sem == 0 && P.scene.n_cube != 0) || P.scene.has_glass) ? 2 : 0) | (P.rng_mode ? 4 : 0);
+    const int geo = ((P.scene.n_tris != 0 && !P.scene.tri_in_lds) ? 1 : 0) | (((sem == 0 && P.scene.n_cube != 0) || P.scene.has_glass || P.scene.tcol_off != 0) ? 2 : 0) | (P.rng_mode ? 4 : 0);
 #define RT_CASE(S, G, M) if (sem == S && geo == G && mode == M) return launch_one<S, G, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm, tile_order, tile_cost)
 #define RT_CASES(S, G) RT_CASE(S, G, 0); RT_CASE(S, G, 1); RT_CASE(S, G, 2)
     RT_CASES(0, 0); RT_CASES(0, 1); RT_CASES(0, 2); RT_CASES(0, 3); RT_CASES(0, 4); RT_CASES(0, 5); RT_CASES(0, 6); RT_CASES(0, 7);

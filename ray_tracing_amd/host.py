@@ -149,22 +149,71 @@ class Camera:
 
 # --------------------------------------------------------------------- mesh
 class SimpleMesh:
-    """src/SimpleMesh.h:22-323 (loadMesh, normalize, resize, transform)."""
+    """src/SimpleMesh.h:22-323."""
 
-    def __init__(self):
+    def __init__(self):                                 # SimpleMesh.h:42
         self._h = C.c_void_p()
+        rc = lib.rt_mesh_create(C.byref(self._h))
+        if rc != 0:
+            raise RtError(rc, "rt_mesh_create")
+
+    @classmethod
+    def _adopt(cls, handle):
+        m = cls.__new__(cls)
+        m._h = handle
+        return m
+
+    def clear(self):                                    # SimpleMesh.h:47-50
+        lib.rt_mesh_clear(self._h)
+
+    def addVertex(self, position, color=(0.0, 0.0, 0.0, 0.0)):   # SimpleMesh.h:93-97
+        p = np.ascontiguousarray(position, dtype=np.float32)
+        c = np.ascontiguousarray(color, dtype=np.float32)
+        assert p.size == 4 and c.size == 4
+        return lib.rt_mesh_add_vertex(self._h, _abi.fptr(p), _abi.fptr(c))
+
+    def addFace(self, idx0, idx1, idx2):                # SimpleMesh.h:99-104
+        return lib.rt_mesh_add_face(self._h, int(idx0), int(idx1), int(idx2))
+
+    def setColor(self, r, g, b, a):                     # SimpleMesh.h:87-91
+        lib.rt_mesh_set_color(self._h, float(r), float(g), float(b), float(a))
+
+    def writeMesh(self, filename):                      # SimpleMesh.h:217-245
+        return lib.rt_mesh_write(self._h, str(filename).encode()) == 0
+
+    @classmethod
+    def joinMeshes(cls, mesh1, mesh2, pose1to2=None):   # SimpleMesh.h:251-288; pose1to2: 4x4, element [r][c]
+        h = C.c_void_p()
+        pose = None
+        if pose1to2 is not None:
+            pose = np.ascontiguousarray(np.asarray(pose1to2, dtype=np.float32).reshape(4, 4).T)   # column-major
+        rc = lib.rt_mesh_join(C.byref(h), mesh1._h, mesh2._h, _abi.fptr(pose) if pose is not None else None)
+        if rc != 0:
+            raise RtError(rc, "rt_mesh_join")
+        return cls._adopt(h)
+
+    @classmethod
+    def sphere(cls, center, scale=1.0, color=(0.0, 0.0, 1.0, 1.0)):   # SimpleMesh.h:293-317
+        h = C.c_void_p()
+        c = np.ascontiguousarray(color, dtype=np.float32)
+        rc = lib.rt_mesh_sphere(C.byref(h), _abi.f3(center), float(scale), _abi.fptr(c))
+        if rc != 0:
+            raise RtError(rc, "rt_mesh_sphere")
+        return cls._adopt(h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:      # lib is None while the interpreter shuts down
             lib.rt_mesh_free(self._h)
             self._h = C.c_void_p()
 
     def loadMesh(self, filename):                       # SimpleMesh.h:145-215
-        if self._h:
-            lib.rt_mesh_free(self._h)
-            self._h = C.c_void_p()
-        rc = lib.rt_mesh_load(C.byref(self._h), str(filename).encode())
-        return rc == 0
+        loaded = C.c_void_p()
+        if lib.rt_mesh_load(C.byref(loaded), str(filename).encode()) != 0:
+            self.clear()                                # :147-148 clear first
+            return False
+        lib.rt_mesh_free(self._h)
+        self._h = loaded
+        return True
 
     def normalize(self):                                # SimpleMesh.h:60-68
         lib.rt_mesh_normalize(self._h)
@@ -197,6 +246,14 @@ class SimpleMesh:
         lib.rt_mesh_to_triangles(self._h, out.ctypes.data)
         return out
 
+    def triangleColors(self):
+        """rgb per face: the mean of its vertex colours (what a COFF file carries,
+        SimpleMesh.h:170-183; the reference's shader ignores them, RayTracing.glsl:275)."""
+        n = lib.rt_mesh_triangle_count(self._h)
+        out = np.zeros((n, 3), dtype=np.float32)
+        lib.rt_mesh_triangle_colors(self._h, out.ctypes.data)
+        return out
+
 
 # ------------------------------------------------------ render-call surface
 class RayTracingComputeShader:
@@ -213,6 +270,7 @@ class RayTracingComputeShader:
         self.camera = camera
         self.shapes = []
         self.triangles = []
+        self.triangle_colors = None                     # None: every triangle has triangle_albedo; else rgb per triangle
         self.semantics = semantics
         self.samples_per_frame = samples_per_frame      # RayTracing.glsl:2,6 (10 x 10)
         self.max_depth = max_depth                      # RayTracing.glsl:300
@@ -247,6 +305,9 @@ class RayTracingComputeShader:
         t = pack(self.triangles, TRIANGLE_DTYPE)
         self._check(lib.rt_upload_shapes(self._ctx, s.ctypes.data if len(s) else None, len(s)))
         self._check(lib.rt_upload_triangles(self._ctx, t.ctypes.data if len(t) else None, len(t)))
+        if self.triangle_colors is not None and len(self.triangle_colors):
+            c = np.ascontiguousarray(self.triangle_colors, dtype=np.float32).reshape(-1, 3)
+            self._check(lib.rt_upload_triangle_colors(self._ctx, c.ctypes.data, len(c)))
 
     def compute(self, x, y, z=1, spp=None, first_sample=None):   # :39-42
         """One dispatch over x * y pixels: samples_per_frame new samples per pixel."""

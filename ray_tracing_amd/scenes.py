@@ -32,6 +32,7 @@ class SceneConfig:
     flags: int = 0
     triangle_albedo: tuple = (1.0, 0.0, 0.0)
     rng: int = 0
+    triangle_colors: object = None       # None, or float32 [n_triangles, 3]
     notes: dict = field(default_factory=dict)
 
 
@@ -174,7 +175,44 @@ def config_cpu_tracer(width=512, height=512, spp=25, max_depth=11, cube_turns=3)
                        sample_mode=_abi.SAMPLE_GRID_COMPAT)
 
 
-CONFIGS = {"cpu_tracer": config_cpu_tracer, "c1": config1, "c2": config2, "c3": config3, "c4": config4, "c5": config5}
+def colored_mesh():
+    """A 20-face icosahedron (SimpleMesh::sphere, SimpleMesh.h:293-317) rebuilt vertex by vertex with a
+    colour per vertex, as a COFF file would carry (SimpleMesh.h:170-183) -> (SimpleTriangles, rgb per face)."""
+    src = host.SimpleMesh.sphere((0.5, 1.2, -2.5), 1.3)
+    pos, _ = src.getVertices()
+    mesh = host.SimpleMesh()
+    for i, p in enumerate(pos):
+        mesh.addVertex(p, ((i % 3) / 2.0, ((i + 1) % 4) / 3.0, ((i * 5) % 7) / 6.0, 1.0))
+    for a, b, c in src.getTriangles():
+        mesh.addFace(a, b, c)
+    return mesh.toSimpleTriangles(), mesh.triangleColors()
+
+
+def config_colored_mesh(width=320, height=200, spp=16, max_depth=6, semantics=SEM_GLSL):
+    """src/main.cpp's shapes with a mesh whose faces have their own albedo instead of the shader's
+    hard-coded red (RayTracing.glsl:275)."""
+    tris, colors = colored_mesh()
+    return SceneConfig("colored_mesh", main_cpp_shapes(), tris, _camera(width, height, (1, 1, 6)),
+                       width, height, spp, max_depth, semantics, triangle_colors=colors)
+
+
+def config_box_sides(width=320, height=200, spp=16, max_depth=6, semantics=SEM_GLSL):
+    """Boxes with three different sides (Box::Box stores them, shape.h:67; the shader reads one,
+    RayTracing.glsl:139): rendered with RT_FLAG_BOX_SIDES."""
+    L, M, Li = host.Lambertian, host.Metal, host.Light
+    shapes = _shapes([
+        host.Box((-1, 9, -2), (10, 1, 6), Li((1.5, 1.5, 1.5))),
+        host.Box((0, -50, 0), (100, 100, 100), L((0.3, 0.9, 0.7))),
+        host.Box((3, 1, -4.5), (1, 2, 0.5), L((0, 1, 1))),
+        host.Box((-2, 0.25, -3), (2.5, 0.5, 1), L((1, 0, 0.5))),
+        host.Box((0.5, 1.5, -7), (6, 3, 0.2), M((0.9, 0.9, 0.9))),
+        host.Circle((0.5, 0.6, -2.5), 0.6, L((0.8, 0.8, 0))),
+    ])
+    return SceneConfig("box_sides", shapes, np.zeros(0, TRIANGLE_DTYPE), _camera(width, height, (1, 1, 6)),
+                       width, height, spp, max_depth, semantics, flags=_abi.FLAG_BOX_SIDES)
+
+
+CONFIGS = {"colored_mesh": config_colored_mesh, "box_sides": config_box_sides, "cpu_tracer": config_cpu_tracer, "c1": config1, "c2": config2, "c3": config3, "c4": config4, "c5": config5}
 
 
 def make_renderer(cfg, device=0):
@@ -186,6 +224,7 @@ def make_renderer(cfg, device=0):
                                       samples_per_frame=cfg.spp, max_depth=cfg.max_depth, seed=cfg.seed, rng=cfg.rng)
     rt.shapes = cfg.shapes
     rt.triangles = cfg.triangles
+    rt.triangle_colors = cfg.triangle_colors
     rt.updateShapeBuffer()
     rt.updateCameraBuffer()
     return rt

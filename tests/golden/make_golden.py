@@ -23,7 +23,7 @@ import ray_tracing_amd as rta          # host-side constructors only (no GPU nee
 from oracle import oracle as orc
 
 W, H, SPP = 64, 36, 16
-DEPTHS = {"c1": 4, "c2": 8, "c3": 10, "c4": 11, "c5": 16, "cpu_tracer": 11}
+DEPTHS = {"c1": 4, "c2": 8, "c3": 10, "c4": 11, "c5": 16, "cpu_tracer": 11, "colored_mesh": 6, "box_sides": 6}
 
 
 def scene(name):
@@ -52,10 +52,10 @@ def main():
                         draws=draws, hashes=hashes, u=us, sincos=sincos, unit_vector=unit, hemisphere=hemi)
 
     # (ii)+(iii) per configuration scene at 64x36, 16 spp: accumulator words, counters, per-bounce hit / material ids
-    for name in ("c1", "c2", "c3", "c4", "c5", "cpu_tracer"):
+    for name in ("c1", "c2", "c3", "c4", "c5", "cpu_tracer", "colored_mesh", "box_sides"):
         cfg = scene(name)
         p = orc.params(W, H, SPP, cfg.max_depth, seed=cfg.seed, semantics=cfg.semantics, sample_mode=cfg.sample_mode,
-                       flags=cfg.flags, triangle_albedo=cfg.triangle_albedo)
+                       flags=cfg.flags, triangle_albedo=cfg.triangle_albedo, triangle_colors=cfg.triangle_colors)
         acc, st = orc.render(cfg.shapes, cfg.triangles, cfg.camera, p)
         hit0, mat0 = orc.trace(cfg.shapes, cfg.triangles, cfg.camera, p, 0)
         hit9, mat9 = orc.trace(cfg.shapes, cfg.triangles, cfg.camera, p, 9)

@@ -13,8 +13,8 @@ import pytest
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 W, H, SPP = 64, 36, 16
-DEPTHS = {"c1": 4, "c2": 8, "c3": 10, "c4": 11, "c5": 16, "cpu_tracer": 11}
-CONFIGS = ("c1", "c2", "c3", "c4", "c5", "cpu_tracer")
+DEPTHS = {"c1": 4, "c2": 8, "c3": 10, "c4": 11, "c5": 16, "cpu_tracer": 11, "colored_mesh": 6, "box_sides": 6}
+CONFIGS = ("c1", "c2", "c3", "c4", "c5", "cpu_tracer", "colored_mesh", "box_sides")
 
 
 def load(name):
@@ -71,7 +71,7 @@ def test_oracle_reproduces_scene_fixture(rta, orc, name):
     assert cfg.shapes.tobytes() == g["shapes"].tobytes() and len(cfg.triangles) == int(g["n_triangles"][0])
     np.testing.assert_array_equal(cfg.camera.view(np.uint32), g["camera"].view(np.uint32))
     p = orc.params(W, H, SPP, cfg.max_depth, seed=cfg.seed, semantics=cfg.semantics, sample_mode=cfg.sample_mode,
-                   flags=cfg.flags, triangle_albedo=cfg.triangle_albedo)
+                   flags=cfg.flags, triangle_albedo=cfg.triangle_albedo, triangle_colors=cfg.triangle_colors)
     acc, st = orc.render(cfg.shapes, cfg.triangles, cfg.camera, p)
     np.testing.assert_array_equal(acc, g["accum"])
     assert [st[k] for k in ("samples", "segments", "diffuse", "specular", "terminal")] == list(g["counters"])

@@ -16,7 +16,7 @@ COUNTERS = ("samples", "segments", "diffuse", "specular", "terminal",
 
 def oracle_params(orc, cfg, **kw):
     args = dict(seed=cfg.seed, semantics=cfg.semantics, sample_mode=cfg.sample_mode, flags=cfg.flags,
-                triangle_albedo=cfg.triangle_albedo, rng=cfg.rng)
+                triangle_albedo=cfg.triangle_albedo, rng=cfg.rng, triangle_colors=cfg.triangle_colors)
     args.update(kw)
     return orc.params(cfg.width, cfg.height, cfg.spp, cfg.max_depth, **args)
 
@@ -279,3 +279,33 @@ def test_headless_cpp_driver_matches_python_host(rta, tmp_path):
     want = rt.readImage()[..., :3]
     rt.close()
     np.testing.assert_array_equal(got.view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+def test_triangle_colours(rta, orc, sem):
+    """One albedo per triangle (vertex colours of a COFF mesh) in place of RayTracing.glsl:275's red, both rule sets."""
+    cfg = rta.scenes.config_colored_mesh(width=203, height=131, spp=8, semantics=sem)
+    check_config(rta, orc, cfg, trace_samples=(0, 5))
+    # uploading triangles again returns to the single colour
+    rt = rta.scenes.make_renderer(cfg)
+    try:
+        rt.triangle_colors = None
+        rt.updateShapeBuffer()
+        rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed)
+        img = rt.resolve(cfg.width, cfg.height)
+        acc, _ = orc.render(cfg.shapes, cfg.triangles, cfg.camera, oracle_params(orc, cfg, triangle_colors=None))
+        np.testing.assert_array_equal(img.view(np.uint32), orc.resolve(acc, cfg.spp, cfg.semantics).view(np.uint32))
+        with pytest.raises(rta.RtError):
+            rt.triangle_colors = np.zeros((3, 3), np.float32)        # wrong count
+            rt.updateShapeBuffer()
+    finally:
+        rt.close()
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+def test_box_with_its_own_sides(rta, orc, sem):
+    """RT_FLAG_BOX_SIDES: a Box has the three sides shape.h:67 stores; without the flag only the first (glsl:139)."""
+    cfg = rta.scenes.config_box_sides(width=203, height=131, spp=8, semantics=sem)
+    check_config(rta, orc, cfg, trace_samples=(0, 5))
+    cfg.flags = 0
+    check_config(rta, orc, cfg, trace_samples=(0,))

@@ -136,3 +136,82 @@ def test_scene_lists(rta):
     c = rta.scenes.cpu_sphere_scene()                 # rayTracer.h:48-54
     assert len(c) == 4 and list(c["material"]["type"]) == [1, 1, 1, 0]
     assert c["transformation"][2][0] == 100 and tuple(c["transformation"][3][12:15]) == (1, 2, -2)
+
+
+def test_mesh_sphere_is_the_icosahedron(rta):
+    # SimpleMesh::sphere, SimpleMesh.h:293-317: 12 vertices at distance scale from the centre, 20 faces,
+    # every vertex used by five faces, every edge shared by two faces with opposite orientation.
+    m = rta.SimpleMesh.sphere((1.0, 2.0, 3.0), 0.5, (0.25, 0.5, 0.75, 1.0))
+    pos, col = m.getVertices()
+    idx = m.getTriangles()
+    assert pos.shape == (12, 4) and idx.shape == (20, 3)
+    np.testing.assert_allclose(np.linalg.norm(pos[:, :3] - [1, 2, 3], axis=1), 0.5, rtol=1e-5)
+    np.testing.assert_array_equal(pos[:, 3], 1.0)
+    np.testing.assert_array_equal(col, np.tile(np.float32([0.25, 0.5, 0.75, 1.0]), (12, 1)))
+    np.testing.assert_array_equal(np.bincount(idx.ravel(), minlength=12), 5)
+    edges = {}
+    for a, b, c in idx.tolist():
+        for e in ((a, b), (b, c), (c, a)):
+            edges[e] = edges.get(e, 0) + 1
+    assert len(edges) == 60 and all(v == 1 and (e[1], e[0]) in edges for e, v in edges.items())
+    np.testing.assert_array_equal(idx[0], [0, 4, 1])                     # SimpleMesh.h:300
+    np.testing.assert_allclose(pos[0, :3], [1 - 0.5 * 0.525731, 2, 3 + 0.5 * 0.850651], rtol=1e-6)   # :298
+
+
+def test_mesh_write_then_load(rta, tmp_path):
+    # writeMesh, SimpleMesh.h:217-245: COFF header, "x y z r g b a" with int() colours, "3 i j k" faces.
+    m = rta.SimpleMesh()
+    m.addVertex((0, 0, 0, 1), (1, 0, 0, 1))
+    m.addVertex((1.5, 0, 0, 1), (0, 2.9, 0, 1))
+    m.addVertex((0, 0.25, 0, 1), (0, 0, 255, 255))
+    m.addVertex((float("nan"), 0, 0, 1), (9, 9, 9, 9))                  # :229-233: non-finite -> zeros
+    assert m.addFace(0, 1, 2) == 0 and m.addFace(2, 1, 0) == 1
+    path = tmp_path / "out.off"
+    assert m.writeMesh(path)
+    assert path.read_text().split("\n") == ["COFF", "4 2 0", "0 0 0 1 0 0 1", "1.5 0 0 0 2 0 1", "0 0.25 0 0 0 255 255",
+                                             "0.0 0.0 0.0 0 0 0 0", "3 0 1 2", "3 2 1 0", ""]
+    back = rta.SimpleMesh()
+    assert back.loadMesh(path)
+    pos, col = back.getVertices()
+    np.testing.assert_array_equal(pos[:3, :3], [[0, 0, 0], [1.5, 0, 0], [0, 0.25, 0]])
+    np.testing.assert_array_equal(col[2], np.float32([0, 0, 255, 255]) / np.float32(255))   # loadMesh :179
+    np.testing.assert_array_equal(back.getTriangles(), [[0, 1, 2], [2, 1, 0]])
+    assert not m.writeMesh(tmp_path / "no_such_dir" / "x.off")             # :220
+    assert not back.loadMesh(tmp_path / "missing.off") and len(back.getTriangles()) == 0   # :147-154
+
+
+def test_mesh_join(rta):
+    # joinMeshes, SimpleMesh.h:251-288: mesh1 transformed by pose1to2, mesh2's indices offset.
+    a = rta.SimpleMesh.sphere((0, 0, 0), 1.0, (1, 0, 0, 1))
+    b = rta.SimpleMesh.sphere((5, 0, 0), 2.0, (0, 1, 0, 1))
+    pose = np.eye(4, dtype=np.float32)
+    pose[:3, :3] = [[0, -1, 0], [1, 0, 0], [0, 0, 1]]
+    pose[:3, 3] = [10, 20, 30]
+    j = rta.SimpleMesh.joinMeshes(a, b, pose)
+    pa, ca = a.getVertices()
+    pb, cb = b.getVertices()
+    pj, cj = j.getVertices()
+    np.testing.assert_allclose(pj[:12], pa @ pose.T, atol=1e-6)
+    np.testing.assert_array_equal(pj[12:], pb)
+    np.testing.assert_array_equal(cj, np.concatenate([ca, cb]))
+    np.testing.assert_array_equal(j.getTriangles(), np.concatenate([a.getTriangles(), b.getTriangles() + 12]))
+    same = rta.SimpleMesh.joinMeshes(a, b)
+    np.testing.assert_array_equal(same.getVertices()[0][:12], pa)
+
+
+def test_mesh_colors_from_coff(rta, tmp_path):
+    # loadMesh of a COFF file keeps colour / 255 per vertex (SimpleMesh.h:170-183); a face's colour is
+    # the mean of its three vertices'.  setColor overwrites all (:87-91).
+    path = tmp_path / "c.off"
+    path.write_text("COFF\n4 2 0\n0 0 0 255 0 0 255\n1 0 0 0 255 0 255\n0 1 0 0 0 255 255\n0 0 1 51 102 153 255\n"
+                    "3 0 1 2\n3 1 2 3\n")
+    m = rta.SimpleMesh()
+    assert m.loadMesh(path)
+    col = m.triangleColors()
+    third = np.float32(1) / np.float32(3)
+    np.testing.assert_allclose(col[0], [third, third, third], rtol=1e-6)
+    np.testing.assert_allclose(col[1], [51 / 255 / 3, (255 + 102) / 255 / 3, (255 + 153) / 255 / 3], rtol=1e-6)
+    m.setColor(0.5, 0.25, 0.125, 1.0)
+    np.testing.assert_array_equal(m.triangleColors(), np.tile(np.float32([0.5, 0.25, 0.125]), (2, 1)))
+    m.clear()
+    assert len(m.getTriangles()) == 0 and m.getVertices()[0].shape == (0, 4)

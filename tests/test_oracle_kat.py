@@ -129,6 +129,37 @@ def test_hit_box_closed_forms(orc):
     assert abs(orc.hit_box((-1, 12, -2), 10.0, (-1, 0, -2.5), (0, 1, 0)) - 7.0) < 1e-5
 
 
+def test_hit_box_with_its_own_sides(orc):
+    """ORC_FLAG_BOX_SIDES: the three sides Box::Box stores (shape.h:67), closed forms per face."""
+    inf = float("inf")
+    c, sides = (1.0, 2.0, 3.0), (4.0, 2.0, 1.0)               # x in [-1,3], y in [1,3], z in [2.5,3.5]
+    assert abs(orc.hit_box3(c, sides, (1.5, 2.25, 10), (0, 0, -1)) - 6.5) < 1e-5
+    assert abs(orc.hit_box3(c, sides, (10, 2.25, 3.1), (-1, 0, 0)) - 7.0) < 1e-5
+    assert abs(orc.hit_box3(c, sides, (2.5, -5, 3.1), (0, 1, 0)) - 6.0) < 1e-5
+    assert orc.hit_box3(c, sides, (2.5, 3.5, 10), (0, 0, -1)) == inf             # above the box: y = 3.5 > 3
+    assert abs(orc.hit_box((1, 2, 3), 4.0, (2.5, 3.5, 10), (0, 0, -1)) - 5.0) < 1e-5   # the shader's 4-cube is hit there
+    # equal sides give the shader's function bit for bit
+    for o, d in (((0.3, 0.2, 5.0), (0.0, 0.0, -1.0)), ((4.0, 0.1, 0.2), (-0.8, 0.0, 0.6))):
+        assert orc.hit_box3((0, 0, 0), (2.0, 2.0, 2.0), o, d) == orc.hit_box((0, 0, 0), 2.0, o, d)
+    np.testing.assert_allclose(orc.box_normal3(c, sides, (1.5, 2.25, 3.5)), [0, 0, 1], atol=2e-7)
+    np.testing.assert_allclose(orc.box_normal3(c, sides, (-1.0, 2.25, 3.1)), [-1, 0, 0], atol=2e-7)
+    np.testing.assert_allclose(orc.box_normal3(c, sides, (2.5, 1.0, 3.1)), [0, -1, 0], atol=2e-7)
+
+
+def test_triangle_colours_replace_the_single_albedo(orc, rta):
+    """With equal colours per triangle the frame equals the one rendered with that triangle_albedo; with
+    different ones it differs."""
+    cfg = rta.scenes.config_colored_mesh(width=64, height=40, spp=4)
+    n = len(cfg.triangles)
+    base = dict(seed=cfg.seed, semantics=cfg.semantics, triangle_albedo=(0.9, 0.4, 0.1))
+    a, _ = orc.render(cfg.shapes, cfg.triangles, cfg.camera, orc.params(64, 40, 4, 6, **base))
+    same = np.tile(np.float32([0.9, 0.4, 0.1]), (n, 1))
+    b, _ = orc.render(cfg.shapes, cfg.triangles, cfg.camera, orc.params(64, 40, 4, 6, triangle_colors=same, **base))
+    np.testing.assert_array_equal(a, b)
+    c, _ = orc.render(cfg.shapes, cfg.triangles, cfg.camera, orc.params(64, 40, 4, 6, triangle_colors=cfg.triangle_colors, **base))
+    assert (a != c).any()
+
+
 def test_hit_cube_closed_forms(rta, orc):
     """Cube::hit of the CPU tracer (scene.h:185-204): unit cube, exact == 0.5 surface test, + axis normal."""
     ident = np.eye(4, dtype=np.float32).T.reshape(-1)
