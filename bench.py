@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel per rank")
     ap.add_argument("--width", type=int, default=0, help="override the frame width (experiments)")
     ap.add_argument("--height", type=int, default=0, help="override the frame height (experiments)")
+    ap.add_argument("--semantics", type=int, default=-1, choices=[-1, 0, 1], help="override the rule set (experiments): 0 CPU tracer, 1 shader")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -110,6 +111,8 @@ def main():
     cfg = rta.scenes.CONFIGS[args.config](**({"width": args.width, "height": args.height} if args.width and args.height else {}))
     if args.spp:
         cfg.spp = args.spp
+    if args.semantics >= 0:
+        cfg.semantics = args.semantics
     shard = parallel.plan(args.shard, rank, world, cfg.spp)
     # With several GPUs consecutive frames alternate between two accumulators (and two contexts bound to
     # them), so that the framebuffer exchange of frame k runs beside the trace of frame k+1.

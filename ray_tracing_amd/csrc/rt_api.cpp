@@ -24,8 +24,8 @@
 namespace rtd {
 hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams& P, const void* blob,
                         uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm,
-                        const uint32_t* tile_order, uint32_t* tile_cost);
-hipError_t launch_tile_order(hipStream_t stream, uint32_t* cost, uint32_t* order, uint32_t n);
+                        const uint32_t* tile_order, uint32_t* tile_cost, uint32_t n_workgroups);
+hipError_t launch_tile_plan(hipStream_t stream, uint32_t* cost, uint32_t* work, uint32_t n, uint32_t extra, uint32_t max_slices, float share);
 hipError_t launch_trace_fill(hipStream_t stream, int32_t* hit, uint32_t* mat, size_t n);
 hipError_t launch_resolve(int sem, hipStream_t stream, const uint32_t* accum, float* out, uint32_t w, uint32_t h,
                           uint32_t samples, int gamma_sqrt, int flip_rows);
@@ -68,11 +68,13 @@ struct rt_ctx {
 
     unsigned long long* d_stats = nullptr;
 
-    // Launch order of the tiles, learnt from the previous frame of the same tiling.
-    uint32_t* d_tile_cost = nullptr;     // per tile: iterations of its longest wave
-    uint32_t* d_tile_order = nullptr;    // tiles, most expensive first
-    uint32_t tile_cap = 0;               // entries allocated
-    uint32_t order_tiles_x = 0, order_tiles_y = 0;   // tiling d_tile_order is valid for (0 = none yet)
+    // Plan of the next launch (which workgroup traces which tile, or which slice of a tile's
+    // samples), made from what the tiles cost in the previous frame of the same tiling.
+    uint32_t* d_tile_cost = nullptr;     // per tile: shader clocks of its slowest wave
+    uint32_t* d_tile_order = nullptr;    // the plan: plan_units entries
+    uint32_t tile_cap = 0;               // tiles allocated for (the plan holds 2 * tile_cap entries)
+    uint32_t order_tiles_x = 0, order_tiles_y = 0;   // tiling the plan is valid for (0 = none yet)
+    uint32_t plan_units = 0;             // workgroups of the planned launch
 
     int compute_units = 0;
 };
@@ -247,7 +249,7 @@ static void build_tree(const std::vector<rt_triangle>& tris, const rtd::SceneLay
             }
             const double R = 1.01 * std::sqrt(r2) + 1e-4;
             w.f[0] = cf[0]; w.f[1] = cf[1]; w.f[2] = cf[2];
-            w.f[3] = std::nextafter((float)(R * R), std::numeric_limits<float>::infinity());
+            w.f[3] = std::nextafter((float)R, std::numeric_limits<float>::infinity());
         }
     }
 }
@@ -588,7 +590,7 @@ static int ensure_tiles(rt_ctx* ctx, const rtd::TraceParams& P)
         RT_HIP(ctx, hipFree(ctx->d_tile_order)); ctx->d_tile_order = nullptr;
         ctx->tile_cap = 0; ctx->order_tiles_x = ctx->order_tiles_y = 0;
         RT_HIP(ctx, hipMalloc(&ctx->d_tile_cost, sizeof(uint32_t) * n));
-        RT_HIP(ctx, hipMalloc(&ctx->d_tile_order, sizeof(uint32_t) * n));
+        RT_HIP(ctx, hipMalloc(&ctx->d_tile_order, sizeof(uint32_t) * 2u * (size_t)n));
         ctx->tile_cap = n;
     }
     return RT_OK;
@@ -596,10 +598,10 @@ static int ensure_tiles(rt_ctx* ctx, const rtd::TraceParams& P)
 
 // One launch of the trace kernel: one workgroup per 16x16-pixel tile.
 static int launch_tiles(rt_ctx* ctx, int mode, rtd::TraceParams& P, uint32_t* accum, int32_t* th, uint32_t* tm,
-                        const uint32_t* order, uint32_t* cost)
+                        const uint32_t* plan, uint32_t* cost, uint32_t n_workgroups)
 {
     RT_HIP(ctx, rtd::launch_trace((int)ctx->cfg.semantics, mode, ctx->stream, P, ctx->d_blob, accum, ctx->d_stats, th, tm,
-                                  order, cost));
+                                  plan, cost, n_workgroups));
     return RT_OK;
 }
 
@@ -620,28 +622,38 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         rc = ensure_tiles(ctx, P);
         if (rc) return rc;
         const uint32_t n_tiles = P.tiles_x * P.tiles_y;
-        // The order learnt from the last frame holds while the tiling stays the same; a new
+        // The plan made from the last frame holds while the tiling stays the same; a new
         // tiling starts from the built-in order and clean costs.
-        const bool have_order = ctx->order_tiles_x == P.tiles_x && ctx->order_tiles_y == P.tiles_y && !getenv("RT_NO_TILE_ORDER");
-        if (!have_order) RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, sizeof(uint32_t) * n_tiles, ctx->stream));
+        const bool have_plan = ctx->order_tiles_x == P.tiles_x && ctx->order_tiles_y == P.tiles_y && !getenv("RT_NO_TILE_ORDER");
+        if (!have_plan) RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, sizeof(uint32_t) * n_tiles, ctx->stream));
+        const uint32_t n_workgroups = have_plan ? ctx->plan_units : n_tiles;
         int32_t* d_timeline = nullptr;
         if (timeline_host) {
-            if (timeline_waves < 4u * n_tiles) return fail(ctx, RT_ERR_INVALID_ARG, "timeline buffer holds %u waves, the launch has %u", timeline_waves, 4u * n_tiles);
-            RT_HIP(ctx, hipMalloc(&d_timeline, sizeof(int32_t) * 16u * n_tiles));
-            RT_HIP(ctx, hipMemsetAsync(d_timeline, 0, sizeof(int32_t) * 16u * n_tiles, ctx->stream));
+            if (timeline_waves < 4u * n_workgroups) return fail(ctx, RT_ERR_INVALID_ARG, "timeline buffer holds %u waves, the launch has %u", timeline_waves, 4u * n_workgroups);
+            RT_HIP(ctx, hipMalloc(&d_timeline, sizeof(int32_t) * 16u * n_workgroups));
+            RT_HIP(ctx, hipMemsetAsync(d_timeline, 0, sizeof(int32_t) * 16u * n_workgroups, ctx->stream));
         }
         rc = launch_tiles(ctx, stats ? 1 : 0, P, accum_ptr(ctx), d_timeline, nullptr,
-                                  have_order ? ctx->d_tile_order : nullptr, ctx->d_tile_cost);
+                          have_plan ? ctx->d_tile_order : nullptr, ctx->d_tile_cost, n_workgroups);
         if (rc) { if (d_timeline) (void)hipFree(d_timeline); return rc; }
         hipError_t le = hipSuccess;
         if (le == hipSuccess && d_timeline) {
-            le = hipMemcpyAsync(timeline_host, d_timeline, sizeof(int32_t) * 16u * n_tiles, hipMemcpyDeviceToHost, ctx->stream);
+            le = hipMemcpyAsync(timeline_host, d_timeline, sizeof(int32_t) * 16u * n_workgroups, hipMemcpyDeviceToHost, ctx->stream);
             if (le == hipSuccess) le = hipStreamSynchronize(ctx->stream);
         }
         if (d_timeline) (void)hipFree(d_timeline);
         RT_HIP(ctx, le);
-        RT_HIP(ctx, rtd::launch_tile_order(ctx->stream, ctx->d_tile_cost, ctx->d_tile_order, n_tiles));
+        // Slices of a tile's sample range are added with integer atomics, which only the shader's
+        // sums allow (a float sum depends on the order of its terms); each keeps at least 16 samples.
+        uint32_t max_slices = 1u;
+        if (ctx->cfg.semantics == RT_SEM_GLSL && spp < (1u << 24) && !getenv("RT_NO_SLICES")) max_slices = std::min(16u, std::max(1u, spp / 16u));
+        const uint32_t extra = max_slices > 1u ? n_tiles : 0u;
+        // A tile is cut when it costs more than a quarter of an even share (measured: 0.5 -> 48 ms, 0.35 -> 45,
+        // 0.25 -> 41, 0.125 -> 41 on the 292-triangle mesh scene; no effect on scenes without expensive tiles).
+        const float share = 0.25f;
+        RT_HIP(ctx, rtd::launch_tile_plan(ctx->stream, ctx->d_tile_cost, ctx->d_tile_order, n_tiles, extra, max_slices, share));
         ctx->order_tiles_x = P.tiles_x; ctx->order_tiles_y = P.tiles_y;
+        ctx->plan_units = n_tiles + extra;
     }
     ctx->accum_samples += spp;
     if (stats) {
@@ -794,7 +806,7 @@ int rt_trace_debug(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t max_de
     e = rtd::launch_trace_fill(ctx->stream, d_hit, d_mat, n);
     // accum is not touched by a TRACE launch; pass any valid pointer.
     if (e == hipSuccess) {
-        rc = launch_tiles(ctx, 2, P, reinterpret_cast<uint32_t*>(d_hit), d_hit, d_mat, nullptr, nullptr);
+        rc = launch_tiles(ctx, 2, P, reinterpret_cast<uint32_t*>(d_hit), d_hit, d_mat, nullptr, nullptr, P.tiles_x * P.tiles_y);
         if (rc) { (void)hipFree(d_hit); (void)hipFree(d_mat); return rc; }
     }
     if (e == hipSuccess) e = hipMemcpyAsync(hit_index_host, d_hit, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);

@@ -33,7 +33,11 @@
 
 namespace rtd {
 
+#ifndef RT_COST_CLOCK
+#define RT_COST_CLOCK 1
+#endif
 struct V3 { float x, y, z; };
+constexpr uint32_t WORK_NONE = 0xffffffffu;      // a plan entry without work
 
 #define RT_DEV static __device__ __forceinline__
 
@@ -323,18 +327,22 @@ RT_DEV void test_triangle(float4 w0, float4 w1, float4 w2, float4 w3, uint32_t n
                    x > 0.0f && y > 0.0f && (x + y) < 1.0f);
 }
 
-// Can the ray touch the bounding sphere nb = {centre.xyz, R^2}?  Decided from the
-// ray's closest approach w = oc - (oc.d) d, whose rounding error grows with |oc| only
-// linearly; the term 1e-6 * |oc|^2 on the right covers it (and a direction that is unit
-// only to 1e-6), R's own slack covers the triangle test's.  A NaN centre never hits.
-RT_DEV bool bound_hit(float4 nb, V3 o, V3 d)
+// Can the ray touch the bounding sphere nb = {centre.xyz, R}?  It does when its line passes
+// within R of the centre, (oc.d)^2 + R^2 >= |oc|^2 for a unit direction, and the sphere is not
+// behind the origin.  The rounding error of the two sides is a few 2^-24 of |oc|^2; the term
+// 1e-6 * |oc|^2 on the right covers it (and a direction that is unit only to 1e-6), R's own
+// slack covers the triangle test's.  A NaN centre never hits.
+template <int SEM>
+RT_DEV bool bound_hit(float4 nb, V3 o, V3 d, uint32_t best_key)
 {
     V3 oc = v3(o.x - nb.x, o.y - nb.y, o.z - nb.z);
     float b = dot(oc, d);
-    V3 w = madd(-b, d, oc);
     float oc2 = dot(oc, oc);
-    float rhs = fma_(1e-6f, oc2, nb.w);
-    return dot(w, w) <= rhs && (b < 0.0f || oc2 <= rhs);
+    float rhs = fma_(1e-6f, oc2, nb.w * nb.w);
+    // Nothing inside the sphere is nearer along the ray than -(b + R): with a hit already nearer than that
+    // (by more than the rounding of b), the sphere cannot hold the closest one.
+    float lim = __uint_as_float(best_key + Window<SEM>::tmin) * -1.00001f;
+    return fma_(b, b, rhs) >= oc2 && (b < 0.0f || oc2 <= rhs) && (b + nb.w) >= lim;
 }
 
 // uvec4(255 * color), RayTracing.glsl:301; negative and NaN give 0, large
@@ -372,27 +380,36 @@ void trace_kernel(const TraceParams P,
                   uint32_t* __restrict__ tile_cost)
 {
     constexpr bool STATS = MODE == 1, TRACE = MODE == 2;
+    constexpr bool COST_CLOCK = RT_COST_CLOCK != 0;        // a tile's cost: shader clocks of its slowest wave, not loop iterations
     constexpr bool TRI_GLOBAL = (GEO & 1) != 0, HAS_CUBE = SEM == 0 && (GEO & 2) != 0, HAS_GLASS = (GEO & 2) != 0, HAS_TCOL = (GEO & 2) != 0, RNG_GLSL = (GEO & 4) != 0;
     extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < P.scene.lds_words; i += BLOCK) lds[i] = blob[i];
-    __syncthreads();
-
     const uint32_t lane = tid & 63u;
     uint32_t n_samples = 0, n_segments = 0, n_diffuse = 0, n_specular = 0, n_terminal = 0, n_tri = 0, n_node = 0, n_iterations = 0;
 
     // One 8x8-pixel tile per wave, four waves (a 16x16 tile) per workgroup; workgroups start in
-    // blockIdx order.  tile_order lists the 16x16 tiles that cost more than twice the mean in the
-    // previous frame of this view first, so that the launch does not end waiting for them; without
-    // it the bottom rows of the frame (ground, objects) go first and the top rows (sky) last.  Any
-    // order gives the same image.  (Handing tiles out dynamically through a device-wide counter
-    // to a resident set of waves was tried: it evens out XCDs that run at different speeds in the
-    // first launches of a process, but costs 10 registers and was 5 % slower in steady state.)
+    // blockIdx order.  `work` is the plan made from the previous frame of this view (tile_plan_kernel):
+    // one entry per workgroup = tile | slice << 24 | (slices - 1) << 28, or WORK_NONE.  Tiles that cost
+    // more than twice the mean come first, so that the launch does not end waiting for them; without a
+    // plan the bottom rows of the frame (ground, objects) go first and the top rows (sky) last.  Under
+    // the shader's rules, whose sums are integers, a very expensive tile is cut into several slices of
+    // the sample range, each its own workgroup, added to the frame with atomics: otherwise the launch
+    // lasts as long as its slowest wave, which walks all samples of its 64 pixels one after another.
+    // Any order and any slicing give the same image.  (Handing tiles out dynamically through a
+    // device-wide counter to a resident set of waves was tried: it evens out XCDs that run at
+    // different speeds in the first launches of a process, but costs 10 registers and was 5 % slower
+    // in steady state.)
+    constexpr bool CAN_SLICE = SEM == 1 && !TRACE;
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    const uint32_t unit = tile_order ? tile_order[blockIdx.x] : (n_tiles - 1u - blockIdx.x);
+    if (unit == WORK_NONE) return;                       // uniform over the workgroup
+    for (uint32_t i = tid; i < P.scene.lds_words; i += BLOCK) lds[i] = blob[i];
+    __syncthreads();
     const uint32_t q = blockIdx.x * 4u + (tid >> 6);
     {
-    const uint32_t slot = q >> 2, sub = q & 3u;
-    const uint32_t tile = tile_order ? tile_order[slot] : (n_tiles - 1u - slot);
+    const uint32_t sub = q & 3u;
+    const uint32_t tile = unit & 0xffffffu;
+    const uint32_t slice = CAN_SLICE ? (unit >> 24) & 15u : 0u, n_slices = CAN_SLICE ? (unit >> 28) + 1u : 1u;
     const uint32_t tile_y = tile / P.tiles_x, tile_x = tile - tile_y * P.tiles_x;
     const uint32_t gx = tile_x * TILE_W + (sub & 1u) * 8u + (lane & 7u);
     const uint32_t row = tile_y * TILE_H + (sub >> 1) * 8u + (lane >> 3);   // ordinal among owned rows
@@ -412,13 +429,14 @@ void trace_kernel(const TraceParams P,
     // Running sums of this pixel: float for SEM 0, uint for SEM 1.
     uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
     uint32_t* const acc_ptr = accum + 4u * (size_t)pixel;
-    if (!TRACE && valid) {
+    if (!TRACE && valid && n_slices == 1u) {
         uint4 v = *reinterpret_cast<const uint4*>(acc_ptr);
         acc0 = v.x; acc1 = v.y; acc2 = v.z;
     }
 
-    uint32_t sample = TRACE ? P.trace_sample : P.first_sample;
-    const uint32_t sample_end = TRACE ? P.trace_sample + 1u : P.first_sample + P.spp;
+    // This workgroup's part of the sample range: all of it, or slice `slice` of `n_slices` nearly equal ones.
+    uint32_t sample = TRACE ? P.trace_sample : P.first_sample + (CAN_SLICE ? P.spp * slice / n_slices : 0u);
+    const uint32_t sample_end = TRACE ? P.trace_sample + 1u : P.first_sample + (CAN_SLICE ? P.spp * (slice + 1u) / n_slices : P.spp);
     bool alive = valid && sample < sample_end;
 
     // Origin of the camera ray of `sample`: RayTracing.glsl:296 (jitter, from
@@ -490,9 +508,9 @@ void trace_kernel(const TraceParams P,
     const bool cull = (P.flags & 1u) == 0u;
     constexpr uint32_t NONE = 0xffffffffu;
 
-    uint32_t iterations = 0;           // wave-uniform
+    uint32_t iterations = 0;           // of this lane
     const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const unsigned long long c_start = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long c_start = (STATS || COST_CLOCK) ? __builtin_amdgcn_s_memtime() : 0ull;
     while (alive) {
         ++iterations;
         // ---- closest hit: Scene::hit (scene.h:232-255) /
@@ -526,19 +544,19 @@ void trace_kernel(const TraceParams P,
         // subtree is entered when the ray of any live lane can touch its sphere.
         for (uint32_t i3 = 0; i3 < L.node_n[3]; ++i3) {
             if (STATS) ++n_node;
-            if (cull && !__any(bound_hit(node3[i3], o, d))) continue;
+            if (cull && !__any(bound_hit<SEM>(node3[i3], o, d, best.key))) continue;
             const uint32_t e2 = min(TREE_FAN * i3 + TREE_FAN, L.node_n[2]);
             for (uint32_t i2 = TREE_FAN * i3; i2 < e2; ++i2) {
                 if (STATS) ++n_node;
-                if (cull && !__any(bound_hit(node2[i2], o, d))) continue;
+                if (cull && !__any(bound_hit<SEM>(node2[i2], o, d, best.key))) continue;
                 const uint32_t e1 = min(TREE_FAN * i2 + TREE_FAN, L.node_n[1]);
                 for (uint32_t i1 = TREE_FAN * i2; i1 < e1; ++i1) {
                     if (STATS) ++n_node;
-                    if (cull && !__any(bound_hit(node1[i1], o, d))) continue;
+                    if (cull && !__any(bound_hit<SEM>(node1[i1], o, d, best.key))) continue;
                     const uint32_t e0 = min(TREE_FAN * i1 + TREE_FAN, L.node_n[0]);
                     for (uint32_t i0 = TREE_FAN * i1; i0 < e0; ++i0) {
                         if (STATS) ++n_node;
-                        if (cull && !__any(bound_hit(node0[i0], o, d))) continue;
+                        if (cull && !__any(bound_hit<SEM>(node0[i0], o, d, best.key))) continue;
 #pragma unroll
                         for (uint32_t k = 0; k < TREE_LEAF; ++k) {
                             const uint32_t ti = TREE_LEAF * i0 + k;
@@ -712,11 +730,16 @@ void trace_kernel(const TraceParams P,
     }
 
     if (!TRACE && valid) {
-        uint4 v; v.x = acc0; v.y = acc1; v.z = acc2; v.w = 0u;
-        *reinterpret_cast<uint4*>(acc_ptr) = v;
+        if (CAN_SLICE && n_slices != 1u) {
+            atomicAdd(acc_ptr, acc0); atomicAdd(acc_ptr + 1, acc1); atomicAdd(acc_ptr + 2, acc2);   // integer sums: any order
+        } else {
+            uint4 v; v.x = acc0; v.y = acc1; v.z = acc2; v.w = 0u;
+            *reinterpret_cast<uint4*>(acc_ptr) = v;
+        }
     }
     // What this tile cost, for the next frame's launch order: the longest of its four waves' loops.
-    if (!TRACE && tile_cost && lane == 0u) atomicMax(&tile_cost[tile], iterations);
+    if (!TRACE && tile_cost && lane == 0u)
+        atomicMax(&tile_cost[tile], (COST_CLOCK ? (uint32_t)((__builtin_amdgcn_s_memtime() - c_start) >> 8) + 1u : iterations) * n_slices);
     if (STATS && trace_hit && lane == 0u) {
         // Diagnostic timeline: start and end of this wave tile's loop (100 MHz ticks), where it ran, how long its loop was.
         int32_t* rec4 = trace_hit + 4u * q;
@@ -726,7 +749,13 @@ void trace_kernel(const TraceParams P,
                             (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 28));                      // XCC_ID
         rec4[3] = (int32_t)iterations;
     }
-    n_iterations += iterations;
+    if (STATS) {
+        // The wave ran as long as its longest lane: the maximum of the lanes' own counts.
+        uint32_t longest = iterations;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) longest = max(longest, (uint32_t)__shfl_down(longest, off, 64));
+        n_iterations += longest;
+    }
     }
 
     if (STATS) {
@@ -742,20 +771,25 @@ void trace_kernel(const TraceParams P,
     }
 }
 
-// Turns the per-tile costs of the frame just traced into the launch order of the next
-// one, and clears the costs.  Tiles that cost more than twice the mean (a mesh in one
-// corner of the frame) go first, so that the launch does not end waiting for them; all
-// other tiles keep the built-in order (bottom rows first), which interleaves long and
-// short tiles on every CU — measured faster than a full longest-first sort, whose tail
-// of short tiles is all start-up latency.  One workgroup.
+// Turns the per-tile costs of the frame just traced into the plan of the next one — one entry per
+// workgroup, see trace_kernel — and clears the costs.  n tiles, n + extra entries.
+//   * A tile whose cost exceeds `share` of what a wave slot would carry if all work were spread
+//     evenly (sum of costs / 2048: four waves per tile, 8192 slots) is cut into up to max_slices
+//     slices; the threshold is raised until the additional entries fit into `extra`.  These go first.
+//   * Tiles that cost more than twice the mean but are not cut (max_slices = 1: float sums, whose
+//     order of addition is part of the result) go next.
+//   * All other tiles keep the built-in order (bottom rows first), which interleaves long and short
+//     tiles on every CU — measured faster than a full longest-first sort, whose tail of short tiles
+//     is all start-up latency.
+// One workgroup.
 __global__ __launch_bounds__(1024)
-void tile_order_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n)
+void tile_plan_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ work, uint32_t n, uint32_t extra, uint32_t max_slices, float share)
 {
-    __shared__ uint32_t scan[1024];
+    __shared__ unsigned long long scan[1024];
     __shared__ unsigned long long total;
-    __shared__ uint32_t n_front;
+    __shared__ uint32_t n_extra;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0u) { total = 0ull; n_front = 0u; }
+    if (tid == 0u) total = 0ull;
     __syncthreads();
     unsigned long long sum = 0ull;
     for (uint32_t i = tid; i < n; i += 1024u) sum += cost[i];
@@ -767,65 +801,58 @@ void tile_order_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ order
     // Position j of the built-in order is tile n-1-j; thread t owns positions [t*chunk, (t+1)*chunk).
     const uint32_t chunk = (n + 1023u) / 1024u;
     const uint32_t j0 = min(n, tid * chunk), j1 = min(n, j0 + chunk);
-    uint32_t keep = 0u;
-    for (uint32_t j = j0; j < j1; ++j) {
-        const uint32_t tile = n - 1u - j;
-        if (cost[tile] > limit) order[atomicAdd(&n_front, 1u)] = tile;
-        else ++keep;
+
+    float target = fmaxf(1.0f, (float)total * (share / 2048.0f));
+    auto slices_of = [&](uint32_t c) -> uint32_t {
+        const uint32_t k = (uint32_t)fminf(ceilf((float)c / target), (float)max_slices);
+        return max(k, 1u);
+    };
+    if (max_slices > 1u && extra > 0u) {
+        for (int round = 0; round < 24; ++round) {
+            __syncthreads();
+            if (tid == 0u) n_extra = 0u;
+            __syncthreads();
+            uint32_t mine = 0u;
+            for (uint32_t j = j0; j < j1; ++j) mine += slices_of(cost[n - 1u - j]) - 1u;
+            if (mine) atomicAdd(&n_extra, mine);
+            __syncthreads();
+            if (n_extra <= extra) break;                 // the same value in every thread
+            target *= 1.5f;
+        }
+        __syncthreads();
+        if (n_extra > extra) max_slices = 1u;
+    } else {
+        max_slices = 1u;
     }
-    scan[tid] = keep;
+
+    // Entries per class, packed 21 bits each: cut tiles' slices, uncut expensive tiles, the rest.
+    unsigned long long mine = 0ull;
+    for (uint32_t j = j0; j < j1; ++j) {
+        const uint32_t c = cost[n - 1u - j];
+        const uint32_t k = max_slices > 1u ? slices_of(c) : 1u;
+        mine += k > 1u ? (unsigned long long)k : (c > limit ? 1ull << 21 : 1ull << 42);
+    }
+    scan[tid] = mine;
     __syncthreads();
     for (uint32_t off = 1u; off < 1024u; off <<= 1) {
-        const uint32_t v = tid >= off ? scan[tid - off] : 0u;
+        const unsigned long long v = tid >= off ? scan[tid - off] : 0ull;
         __syncthreads();
         scan[tid] += v;
         __syncthreads();
     }
-    uint32_t at = n_front + scan[tid] - keep;
+    const unsigned long long all = scan[1023], before = scan[tid] - mine;
+    const uint32_t n0 = (uint32_t)(all & 0x1fffffu), n1 = (uint32_t)((all >> 21) & 0x1fffffu), n2 = (uint32_t)(all >> 42);
+    uint32_t at0 = (uint32_t)(before & 0x1fffffu), at1 = n0 + (uint32_t)((before >> 21) & 0x1fffffu), at2 = n0 + n1 + (uint32_t)(before >> 42);
     for (uint32_t j = j0; j < j1; ++j) {
-        const uint32_t tile = n - 1u - j;
-        if (!(cost[tile] > limit)) order[at++] = tile;
+        const uint32_t tile = n - 1u - j, c = cost[tile];
+        const uint32_t k = max_slices > 1u ? slices_of(c) : 1u;
+        if (k > 1u) { for (uint32_t sl = 0u; sl < k; ++sl) work[at0++] = tile | (sl << 24) | ((k - 1u) << 28); }
+        else if (c > limit) work[at1++] = tile;
+        else work[at2++] = tile;
     }
+    for (uint32_t i = n0 + n1 + n2 + tid; i < n + extra; i += 1024u) work[i] = WORK_NONE;
     __syncthreads();
     for (uint32_t i = tid; i < n; i += 1024u) cost[i] = 0u;
-}
-
-// Full longest-first order (counting sort over 256 cost classes).  Kept for experiments.
-__global__ __launch_bounds__(1024)
-void tile_order_lpt_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n)
-{
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t scan[256];
-    __shared__ uint32_t max_cost;
-    const uint32_t tid = threadIdx.x;
-    if (tid < 256u) hist[tid] = 0u;
-    if (tid == 0u) max_cost = 1u;
-    __syncthreads();
-    uint32_t m = 0u;
-    for (uint32_t i = tid; i < n; i += 1024u) m = max(m, cost[i]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, off, 64));
-    if ((tid & 63u) == 0u) atomicMax(&max_cost, m);
-    __syncthreads();
-    const float scale = 255.0f / (float)max_cost;
-    auto cls = [&](uint32_t c) { return 255u - min(255u, (uint32_t)((float)c * scale)); };
-    for (uint32_t i = tid; i < n; i += 1024u) atomicAdd(&hist[cls(cost[i])], 1u);
-    __syncthreads();
-    if (tid < 256u) scan[tid] = hist[tid];
-    __syncthreads();
-    for (uint32_t off = 1u; off < 256u; off <<= 1) {
-        uint32_t v = 0u;
-        if (tid < 256u && tid >= off) v = scan[tid - off];
-        __syncthreads();
-        if (tid < 256u) scan[tid] += v;
-        __syncthreads();
-    }
-    if (tid < 256u) hist[tid] = scan[tid] - hist[tid];
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += 1024u) {
-        order[atomicAdd(&hist[cls(cost[i])], 1u)] = i;
-        cost[i] = 0u;
-    }
 }
 
 // TRACE launches first mark every entry "path already over".
@@ -903,19 +930,17 @@ static hipError_t launch_one(dim3 grid, size_t lds_bytes, hipStream_t stream, co
     return hipGetLastError();
 }
 
-hipError_t launch_tile_order(hipStream_t stream, uint32_t* cost, uint32_t* order, uint32_t n)
+hipError_t launch_tile_plan(hipStream_t stream, uint32_t* cost, uint32_t* work, uint32_t n, uint32_t extra, uint32_t max_slices, float share)
 {
-    static const bool lpt = getenv("RT_TILE_LPT") != nullptr;
-    if (lpt) hipLaunchKernelGGL(tile_order_lpt_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n);
-    else hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n);
+    hipLaunchKernelGGL(tile_plan_kernel, dim3(1), dim3(1024), 0, stream, cost, work, n, extra, max_slices, share);
     return hipGetLastError();
 }
 
 hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams& P, const void* blob,
                         uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm,
-                        const uint32_t* tile_order, uint32_t* tile_cost)
+                        const uint32_t* tile_order, uint32_t* tile_cost, uint32_t n_workgroups)
 {
-    const dim3 grid(P.tiles_x * P.tiles_y);
+    const dim3 grid(n_workgroups);
     const float4* b = static_cast<const float4*>(blob);
     const size_t lds_bytes = (size_t)P.scene.lds_words * 16u;
     const int geo = ((P.scene.n_tris != 0 && !P.scene.tri_in_lds) ? 1 : 0) | (((sem == 0 && P.scene.n_cube != 0) || P.scene.has_glass || P.scene.tcol_off != 0) ? 2 : 0) | (P.rng_mode ? 4 : 0);

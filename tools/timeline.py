@@ -11,9 +11,9 @@ rt = rta.scenes.make_renderer(cfg)
 n_tiles = ((cfg.width + 15) // 16) * ((cfg.height + 15) // 16)
 for rep in range(3):
     rt.resetAccum()
-    tl = np.zeros((n_tiles * 4, 4), dtype=np.int32)
+    tl = np.zeros((n_tiles * 8, 4), dtype=np.int32)
     st = _abi.Stats()
-    rt._check(_abi.lib.rt_render_timeline(rt._ctx, cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, 0, 0, C.byref(st), tl.ctypes.data, n_tiles * 4))
+    rt._check(_abi.lib.rt_render_timeline(rt._ctx, cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, 0, 0, C.byref(st), tl.ctypes.data, n_tiles * 8))
 t = tl.view(np.uint32)
 start, end, hw, it = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64), t[:, 2], t[:, 3]
 live = it > 0
