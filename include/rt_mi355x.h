@@ -153,6 +153,7 @@ typedef struct rt_stats {
     uint64_t triangle_tests_done;  /* ray-triangle tests this library executed (it culls by bounding spheres) */
     uint64_t bound_tests_done;     /* ray-bounding-sphere tests it executed to do so */
     uint64_t wave_iterations;      /* loop iterations summed over waves: segments / (64 * this) = lane use */
+    uint64_t work_units;           /* workgroups that traced: the tiles, plus one per extra slice of a tile's sample range */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

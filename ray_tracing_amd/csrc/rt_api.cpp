@@ -673,6 +673,7 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         stats->triangle_tests_done = h[rtd::ST_TRI_TESTS];
         stats->bound_tests_done = h[rtd::ST_NODE_TESTS];
         stats->wave_iterations = h[rtd::ST_WAVE_ITERS];
+        stats->work_units = h[rtd::ST_UNITS];
     }
     return RT_OK;
 }

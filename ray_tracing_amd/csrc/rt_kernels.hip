@@ -760,7 +760,8 @@ void trace_kernel(const TraceParams P,
 
     if (STATS) {
         // Sum over the wave with cross-lane shuffles, one atomic per wave and counter.
-        uint32_t c[ST_COUNT] = { n_samples, n_segments, n_diffuse, n_specular, n_terminal, n_tri, n_node, (lane == 0u) ? n_iterations : 0u };
+        uint32_t c[ST_COUNT] = { n_samples, n_segments, n_diffuse, n_specular, n_terminal, n_tri, n_node, (lane == 0u) ? n_iterations : 0u,
+                                 (tid == 0u) ? 1u : 0u };
 #pragma unroll
         for (int k = 0; k < ST_COUNT; ++k) {
             unsigned long long v = c[k];

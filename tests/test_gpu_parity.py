@@ -309,3 +309,41 @@ def test_box_with_its_own_sides(rta, orc, sem):
     check_config(rta, orc, cfg, trace_samples=(0, 5))
     cfg.flags = 0
     check_config(rta, orc, cfg, trace_samples=(0,))
+
+
+def test_sliced_sample_ranges(rta, orc):
+    """Under the shader's rules a tile that cost much more than the others in the previous frame is traced by
+    several workgroups, each a slice of the sample range, added with integer atomics: same words, same counters."""
+    cfg = rta.scenes.config3(width=323, height=181, spp=96, max_depth=6)
+    rt = rta.scenes.make_renderer(cfg)
+    try:
+        acc, ostats = orc.render(cfg.shapes, cfg.triangles, cfg.camera, oracle_params(orc, cfg))
+        ref = orc.resolve(acc, cfg.spp, cfg.semantics)
+        n_tiles = ((cfg.width + 15) // 16) * ((cfg.height + 15) // 16)
+        units = []
+        for frame in range(3):
+            rt.resetAccum()
+            st = rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, stats=True)
+            img = rt.resolve(cfg.width, cfg.height)
+            np.testing.assert_array_equal(img.view(np.uint32), ref.view(np.uint32))
+            assert {k: st[k] for k in COUNTERS} == {k: ostats[k] for k in COUNTERS}
+            units.append(st["work_units"])
+        assert units[0] == n_tiles and units[1] > n_tiles and units[2] > n_tiles, units
+        # two half frames on top of each other (the second one sliced too) = one frame
+        rt.resetAccum()
+        rt.render(cfg.width, cfg.height, 48, cfg.max_depth, cfg.seed, first_sample=0)
+        rt.render(cfg.width, cfg.height, 48, cfg.max_depth, cfg.seed, first_sample=48)
+        np.testing.assert_array_equal(rt.resolve(cfg.width, cfg.height).view(np.uint32), ref.view(np.uint32))
+        # the CPU tracer's float sums are never sliced: their order of addition is part of the result
+    finally:
+        rt.close()
+    cfg0 = rta.scenes.config3(width=323, height=181, spp=96, max_depth=6)
+    cfg0.semantics = 0
+    rt = rta.scenes.make_renderer(cfg0)
+    try:
+        for frame in range(2):
+            rt.resetAccum()
+            st = rt.render(cfg0.width, cfg0.height, cfg0.spp, cfg0.max_depth, cfg0.seed, stats=True)
+            assert st["work_units"] == n_tiles
+    finally:
+        rt.close()
