@@ -99,6 +99,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 path on a box with one GPU: RT_BENCH_BACKEND=gloo RT_BENCH_DEVICE=0 puts all
+    # ranks on one device and exchanges through gloo.  Never set by the driver; the numbers mean nothing.
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    if "RT_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["RT_BENCH_DEVICE"])
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
@@ -106,8 +111,15 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend, **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
 
+    verbose = "RT_BENCH_VERBOSE" in os.environ
+
+    def say(*a):
+        if verbose:
+            print(f"[rank {rank}]", *a, file=sys.stderr, flush=True)
+
+    say("process group up")
     cfg = rta.scenes.CONFIGS[args.config](**({"width": args.width, "height": args.height} if args.width and args.height else {}))
     if args.spp:
         cfg.spp = args.spp
@@ -150,8 +162,10 @@ def main():
         pending = None
         for k in range(n):
             nxt = trace(k, events[k] if events else None)
+            say("frame", k, "queued")
             if pending is not None:
                 finish(pending)               # frame k-1: after frame k's trace is queued
+                say("frame", k - 1, "finished")
             if n_buf == 1:
                 finish(nxt); nxt = None
             pending = nxt
@@ -162,17 +176,22 @@ def main():
     rts[0].resetAccum()
     stats = rts[0].render(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, first_sample=shard.first_sample, stats=True)
 
+    say("stats launch done")
     run(args.warmup)
+    say("warmup done")
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    say("timed region starts")
     t0 = time.perf_counter()
     run(args.steps, events)
+    say("timed steps queued")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    say("timed steps done")
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")

@@ -70,4 +70,8 @@ def reduce_framebuffer(accum_words, semantics, dst=0, group=None, async_op=False
     that the exchange over xGMI runs beside it."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return None
-    return dist.reduce(accum_view(accum_words, semantics), dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    t = accum_view(accum_words, semantics)
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no reduce for device tensors; its all_reduce gives rank `dst` the same sum (rehearsals only)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
