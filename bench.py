@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 # (advance, normal, randomOnHalfUnitShere :64-80, throughput) ~90, a mirror bounce ~30,
 # a terminal event (light / miss) ~3.
 F_SPHERE, F_BOX, F_TRI = 20, 58, 32
-F_BOUND = 26                          # one ray / bounding-sphere test of the triangle tree (3 sub, 3 dots, 3 fma, 1 fma)
+F_BOUND = 20                          # one ray / bounding-sphere test of the triangle tree (3 sub, 2 dots, R*R, 2 fma, limit mul, add)
 F_CAMERA, F_DIFFUSE, F_SPECULAR, F_TERMINAL = 25 + 2 * 11, 90, 30, 3
 PEAK_FP32_VECTOR_TFLOPS = 157.3       # 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
