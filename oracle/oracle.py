@@ -62,6 +62,7 @@ def _load():
     lib.orc_sincos2pi.restype = None; lib.orc_sincos2pi.argtypes = [C.c_float, fp, fp]
     lib.orc_unit_vector.restype = None; lib.orc_unit_vector.argtypes = [C.c_float, C.c_float, fp]
     lib.orc_hemisphere_glsl.restype = None; lib.orc_hemisphere_glsl.argtypes = [fp, C.c_float, C.c_float, fp]
+    lib.orc_glass_direction.restype = None; lib.orc_glass_direction.argtypes = [fp, fp, C.c_float, C.c_float, fp]
     lib.orc_hit_sphere.restype = C.c_float; lib.orc_hit_sphere.argtypes = [fp, C.c_float, fp, fp]
     lib.orc_hit_box.restype = C.c_float; lib.orc_hit_box.argtypes = [fp, C.c_float, fp, fp]
     lib.orc_hit_triangle.restype = C.c_float; lib.orc_hit_triangle.argtypes = [vp, fp, fp]
@@ -154,6 +155,12 @@ def unit_vector(u1, u2):
 def hemisphere_glsl(n, u1, u2):
     o = _f(0, 0, 0)
     lib.orc_hemisphere_glsl(_f(*n), u1, u2, o)
+    return np.array(o[:], dtype=np.float32)
+
+
+def glass_direction(n, d, ior, u1):
+    o = _f(0, 0, 0)
+    lib.orc_glass_direction(_f(*n), _f(*d), ior, u1, o)
     return np.array(o[:], dtype=np.float32)
 
 

@@ -487,6 +487,12 @@ static inline v3 triangle_color(const tracer* T, int i)
     return V(c[0], c[1], c[2]);
 }
 
+void orc_glass_direction(const float n[3], const float d[3], float ior, float u1, float out[3])
+{
+    v3 r = glass_direction(V(n[0], n[1], n[2]), V(d[0], d[1], d[2]), ior, u1);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
 /* Outcome of the surface interaction at one hit. */
 enum { EV_SCATTER = 0, EV_EMIT = 1 };
 

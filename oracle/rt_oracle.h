@@ -98,6 +98,8 @@ void     orc_glsl_seed(uint64_t seed, uint32_t width, uint32_t height, uint32_t 
 void     orc_sincos2pi(float u, float* c, float* s);
 void     orc_unit_vector(float u1, float u2, float out[3]);
 void     orc_hemisphere_glsl(const float n[3], float u1, float u2, float out[3]);
+/* The dielectric's new direction (not normalised): mirrored when u1 < Schlick's reflectance, else refracted. */
+void     orc_glass_direction(const float n[3], const float d[3], float ior, float u1, float out[3]);
 float    orc_hit_sphere(const float center[3], float radius, const float o[3], const float d[3]);
 float    orc_hit_box(const float center[3], float scale, const float o[3], const float d[3]);
 float    orc_hit_box3(const float center[3], const float sides[3], const float o[3], const float d[3]);

@@ -371,3 +371,26 @@ def test_progressive_chunks_equal_one_shot(rta, orc):
     for first, n in ((0, 4), (4, 4), (8, 8)):
         acc, _ = orc.render(cfg.shapes, cfg.triangles, cfg.camera, orc.params(24, 24, n, 5, first_sample=first), accum=acc)
     np.testing.assert_array_equal(acc, one)
+
+
+def test_dielectric_obeys_snell_and_schlick(orc):
+    """The dielectric (material type 3, defined by this build: the reference has no refraction) at a surface with
+    normal +z: refracted rays obey sin(t) = sin(i) / ior and stay in the plane of incidence; the mirrored ray is
+    reflect(d, n); the reflectance is Schlick's, r0 = ((1 - ior) / (1 + ior))^2 at normal incidence, 1 at grazing."""
+    n = (0.0, 0.0, 1.0)
+    for ior in (1.5, 1.33, 2.4):
+        for deg in (0.0, 10.0, 35.0, 60.0, 80.0):
+            si, ci = np.sin(np.radians(deg)), np.cos(np.radians(deg))
+            d = (float(si), 0.0, float(-ci))
+            refr = orc.glass_direction(n, d, ior, 0.999999)            # u1 above any reflectance below grazing
+            refr = refr / np.linalg.norm(refr)
+            assert abs(refr[1]) < 1e-7 and refr[2] < 0
+            assert abs(refr[0] - si / ior) < 2e-6                       # Snell
+            mirr = orc.glass_direction(n, d, ior, 0.0)
+            np.testing.assert_allclose(mirr, [si, 0.0, ci], atol=2e-7)  # reflect(d, n), utils.h:62-64
+    r0 = ((1 - 1.5) / (1 + 1.5)) ** 2                                   # 0.04
+    d0 = (0.0, 0.0, -1.0)
+    assert orc.glass_direction(n, d0, 1.5, r0 * 0.99)[2] > 0            # below r0: mirrored
+    assert orc.glass_direction(n, d0, 1.5, r0 * 1.01)[2] < 0            # above: refracted
+    graze = (float(np.sin(np.radians(89.9))), 0.0, float(-np.cos(np.radians(89.9))))
+    assert orc.glass_direction(n, graze, 1.5, 0.98)[2] > 0              # reflectance -> 1 at grazing incidence
