@@ -232,10 +232,13 @@ int rt_render_stats(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp,
                     uint32_t max_depth, uint64_t seed, uint32_t first_sample,
                     uint32_t grid_n, rt_stats* out);
 
-/* Diagnostic: rt_render_stats that also records, per wave of the launch (four per
- * 16x16-pixel tile, in launch order), {start, end} of its loop in 100 MHz ticks, the
- * hardware id register and the loop's length.  timeline_host: 4 int32 per wave,
- * timeline_waves = capacity in waves.  No counterpart in the reference. */
+/* Diagnostic: a render that also records, per wave of the launch (four per workgroup
+ * of the launch plan, in launch order), {start, end} of its loop in 100 MHz ticks, its
+ * shader clocks / 16 with the XCC id in the top four bits, and the loop's length.
+ * timeline_host: 4 int32 per wave, timeline_waves = capacity in waves (8 per 16x16
+ * tile always suffice).  out = NULL: the plain render kernel, whose timing the work
+ * counters do not disturb; else also the counters of rt_render_stats.  No counterpart
+ * in the reference. */
 int rt_render_timeline(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp,
                        uint32_t max_depth, uint64_t seed, uint32_t first_sample,
                        uint32_t grid_n, rt_stats* out, int32_t* timeline_host,

@@ -64,6 +64,7 @@ struct TraceParams {
     uint32_t owned_rows;       // rows of this shard
     uint32_t trace_sample;     // TRACE launches: the one sample to follow
     uint32_t tiles_x, tiles_y; // 16x16-pixel tiles covering width x owned_rows
+    uint32_t group_waves;      // waves per workgroup: 4 (one 16x16 tile) or 1 (one 8x8 quarter of it)
     uint32_t rng_mode;         // 0 counter hash, 1 the shader's random() (RayTracing.glsl:44-51)
     uint32_t glsl_seed32;      // low word of the seed: the shader's `time` is (this + frame) / 10000
     float    inv_w, inv_h;     // 1 / width, 1 / height (RayTracing.glsl:9 divides the invocation id by them)

@@ -401,11 +401,13 @@ void trace_kernel(const TraceParams P,
     // in steady state.)
     constexpr bool CAN_SLICE = SEM == 1 && !TRACE;
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
-    const uint32_t unit = tile_order ? tile_order[blockIdx.x] : (n_tiles - 1u - blockIdx.x);
+    // A workgroup is the four waves of one entry, or (P.group_waves = 1) a single wave, four consecutive
+    // workgroups sharing an entry.
+    const uint32_t q = blockIdx.x * P.group_waves + (tid >> 6);
+    const uint32_t unit = tile_order ? tile_order[q >> 2] : (n_tiles - 1u - (q >> 2));
     if (unit == WORK_NONE) return;                       // uniform over the workgroup
-    for (uint32_t i = tid; i < P.scene.lds_words; i += BLOCK) lds[i] = blob[i];
+    for (uint32_t i = tid; i < P.scene.lds_words; i += blockDim.x) lds[i] = blob[i];
     __syncthreads();
-    const uint32_t q = blockIdx.x * 4u + (tid >> 6);
     {
     const uint32_t sub = q & 3u;
     const uint32_t tile = unit & 0xffffffu;
@@ -509,7 +511,7 @@ void trace_kernel(const TraceParams P,
     constexpr uint32_t NONE = 0xffffffffu;
 
     uint32_t iterations = 0;           // of this lane
-    const unsigned long long t_start = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long t_start = (!TRACE && trace_hit) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const unsigned long long c_start = (STATS || COST_CLOCK) ? __builtin_amdgcn_s_memtime() : 0ull;
     while (alive) {
         ++iterations;
@@ -740,7 +742,7 @@ void trace_kernel(const TraceParams P,
     // What this tile cost, for the next frame's launch order: the longest of its four waves' loops.
     if (!TRACE && tile_cost && lane == 0u)
         atomicMax(&tile_cost[tile], (COST_CLOCK ? (uint32_t)((__builtin_amdgcn_s_memtime() - c_start) >> 8) + 1u : iterations) * n_slices);
-    if (STATS && trace_hit && lane == 0u) {
+    if (!TRACE && trace_hit && lane == 0u) {
         // Diagnostic timeline: start and end of this wave tile's loop (100 MHz ticks), where it ran, how long its loop was.
         int32_t* rec4 = trace_hit + 4u * q;
         rec4[0] = (int32_t)(uint32_t)t_start;
@@ -761,7 +763,7 @@ void trace_kernel(const TraceParams P,
     if (STATS) {
         // Sum over the wave with cross-lane shuffles, one atomic per wave and counter.
         uint32_t c[ST_COUNT] = { n_samples, n_segments, n_diffuse, n_specular, n_terminal, n_tri, n_node, (lane == 0u) ? n_iterations : 0u,
-                                 (tid == 0u) ? 1u : 0u };
+                                 (tid == 0u && (q & 3u) == 0u) ? 1u : 0u };
 #pragma unroll
         for (int k = 0; k < ST_COUNT; ++k) {
             unsigned long long v = c[k];
@@ -926,7 +928,7 @@ static hipError_t launch_one(dim3 grid, size_t lds_bytes, hipStream_t stream, co
                              uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm,
                              const uint32_t* tile_order, uint32_t* tile_cost)
 {
-    hipLaunchKernelGGL((trace_kernel<SEM, GEO, MODE>), grid, dim3(BLOCK), lds_bytes, stream, P, blob, accum, st, th, tm,
+    hipLaunchKernelGGL((trace_kernel<SEM, GEO, MODE>), grid, dim3(64u * P.group_waves), lds_bytes, stream, P, blob, accum, st, th, tm,
                        tile_order, tile_cost);
     return hipGetLastError();
 }
@@ -941,7 +943,7 @@ hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams
                         uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm,
                         const uint32_t* tile_order, uint32_t* tile_cost, uint32_t n_workgroups)
 {
-    const dim3 grid(n_workgroups);
+    const dim3 grid(n_workgroups * (4u / P.group_waves));
     const float4* b = static_cast<const float4*>(blob);
     const size_t lds_bytes = (size_t)P.scene.lds_words * 16u;
     const int geo = ((P.scene.n_tris != 0 && !P.scene.tri_in_lds) ? 1 : 0) | (((sem == 0 && P.scene.n_cube != 0) || P.scene.has_glass || P.scene.tcol_off != 0) ? 2 : 0) | (P.rng_mode ? 4 : 0);

@@ -9,12 +9,14 @@ cfg = rta.scenes.CONFIGS[name]()
 if len(sys.argv) > 2: cfg.spp = int(sys.argv[2])
 rt = rta.scenes.make_renderer(cfg)
 n_tiles = ((cfg.width + 15) // 16) * ((cfg.height + 15) // 16)
-for rep in range(3):
+reps = int(os.environ.get('TL_REPS', '3'))
+for rep in range(reps):
     rt.resetAccum()
     tl = np.zeros((n_tiles * 8, 4), dtype=np.int32)
     st = _abi.Stats()
-    rt._check(_abi.lib.rt_render_timeline(rt._ctx, cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, 0, 0, C.byref(st), tl.ctypes.data, n_tiles * 8))
+    rt._check(_abi.lib.rt_render_timeline(rt._ctx, cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, 0, 0, (C.byref(st) if os.environ.get('TL_STATS') else None), tl.ctypes.data, n_tiles * 8))
 t = tl.view(np.uint32)
+if os.environ.get('TL_DUMP'): np.save(os.environ['TL_DUMP'], t)
 start, end, hw, it = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64), t[:, 2], t[:, 3]
 live = it > 0
 t0 = start[live].min(); start = (start - t0) * 0.01; end = (end - t0) * 0.01          # microseconds
@@ -29,6 +31,10 @@ for k in range(8):
     m = live & (xcc == k)
     if m.any():
         print(f"  XCC {k}: {int(m.sum()):5d} waves, first start {start[m].min():7.1f}, last start {start[m].max():7.1f}, last end {end[m].max():7.1f} us, sum of wave times {(end[m]-start[m]).sum():9.0f} us, iterations {int(it[m].sum())}")
+print("  resident waves per XCC over time:")
+for a, b in zip(edges[:-1], edges[1:]):
+    mid = (a + b) / 2
+    print(f"  t={mid:8.1f} us ", " ".join(f"{int(((start <= mid) & (end > mid) & live & (xcc == k)).sum()):5d}" for k in range(8)))
 blk = np.arange(len(hw)) // 4
 print("  XCC of the first 16 workgroups:", [int(xcc[4*b]) for b in range(16)])
 busy = (end[live] - start[live]).sum()
