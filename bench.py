@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--width", type=int, default=0, help="override the frame width (experiments)")
     ap.add_argument("--height", type=int, default=0, help="override the frame height (experiments)")
     ap.add_argument("--semantics", type=int, default=-1, choices=[-1, 0, 1], help="override the rule set (experiments): 0 CPU tracer, 1 shader")
+    ap.add_argument("--mesh", default="", help="c3 only: the mesh file under ray_tracing_amd/data (default Bunny-LowPoly.off; bunny.off has 4 968 triangles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -120,7 +121,12 @@ def main():
             print(f"[rank {rank}]", *a, file=sys.stderr, flush=True)
 
     say("process group up")
-    cfg = rta.scenes.CONFIGS[args.config](**({"width": args.width, "height": args.height} if args.width and args.height else {}))
+    overrides = {"width": args.width, "height": args.height} if args.width and args.height else {}
+    if args.mesh:
+        if args.config != "c3":
+            raise SystemExit("--mesh applies to --config c3 only")
+        overrides["mesh"] = args.mesh
+    cfg = rta.scenes.CONFIGS[args.config](**overrides)
     if args.spp:
         cfg.spp = args.spp
     if args.semantics >= 0:

@@ -1,4 +1,4 @@
-"""ctypes binding of the CPU oracle (oracle/_ref/librt_oracle.so).
+"""ctypes binding of the CPU oracle (oracle/_build/librt_oracle.so).
 
 Test infrastructure: imported only by tests/, the smoke check and the
 cpu_baseline leg of bench.py — never by the renderer.
@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_ref", "librt_oracle.so")
+LIB_PATH = os.path.join(_HERE, "_build", "librt_oracle.so")
 
 SEM_CPU, SEM_GLSL = 0, 1
 SAMPLE_JITTER, SAMPLE_GRID, SAMPLE_GRID_COMPAT = 0, 1, 2

@@ -91,8 +91,12 @@ static inline float gmax(float x, float y) { return (x < y) ? y : x; }
  * The reference's streams cannot be reproduced (utils.h:8-9: mt19937 seeded
  * from random_device and shared by all threads; RayTracing.glsl:8-9,44-51:
  * a sin-hash of wall-clock time).  What is kept is their structure: one
- * stream per (seed, pixel, sample), indexed by draw number.  draw i of a path
- * is hash32(key + i * 0x9E3779B9) with key = f(seed, pixel, sample). */
+ * stream per (seed, pixel, sample), indexed by draw number.  The path has the key
+ * hash32(seed_key ^ pixel) + sample * 0x85EBCA6B; its draws come in pairs (every event of a path
+ * needs two) from one hashed word per pair: x = hash32(key + (i / 2) * 0x9E3779B9) gives draw i,
+ * i even, from its top 24 bits and draw i + 1 from the top 24 bits of x * 0x2C1B3C6D.  The two
+ * steps differ so that no (sample, pair) meets another one's hash input: s * 0x85EBCA6B +
+ * p * 0x9E3779B9 repeats only for sample numbers 17 million apart (pairs up to 128 apart). */
 uint32_t orc_hash32(uint32_t x)
 {
     x ^= x >> 16; x *= 0x7feb352du;
@@ -108,15 +112,15 @@ static uint32_t seed_key(uint64_t seed)
 
 uint32_t orc_path_key(uint64_t seed, uint32_t pixel_index, uint32_t sample)
 {
-    uint32_t h1 = orc_hash32(seed_key(seed) ^ pixel_index);
-    return orc_hash32(h1 ^ sample);
+    return orc_hash32(seed_key(seed) ^ pixel_index) + sample * 0x85ebca6bu;
 }
 
 /* Uniform in [0,1) with 24 bits, like random() of RayTracing.glsl:44-51. */
 float orc_draw(uint32_t key, uint32_t index)
 {
-    uint32_t h = orc_hash32(key + index * 0x9e3779b9u);
-    return (float)(h >> 8) * 0x1p-24f;
+    uint32_t x = orc_hash32(key + (index >> 1) * 0x9e3779b9u);
+    if (index & 1u) x *= 0x2c1b3c6du;
+    return (float)(x >> 8) * 0x1p-24f;
 }
 
 /* random() of RayTracing.glsl:44-51, the shader's own stream: the state is the vec3 `seed`
@@ -683,7 +687,7 @@ static ray camera_ray(const float* cam, const orc_params* p, uint32_t seed_k, ui
     float step = cam[19];
     v3 pos = cam3(cam, 0), up = cam3(cam, 12), right = cam3(cam, 16);
     v3 pc = pixel_corner(cam, gx, gy);
-    g->key = orc_hash32(orc_hash32(seed_k ^ (gy * p->width + gx)) ^ sample);
+    g->key = orc_hash32(seed_k ^ (gy * p->width + gx)) + sample * 0x85ebca6bu;      /* orc_path_key */
     g->glsl = p->rng == ORC_RNG_GLSL;
     if (g->glsl) orc_glsl_seed(p->seed, p->width, p->height, gx, gy, sample, g->s);
     v3 origin;

@@ -134,22 +134,13 @@ static inline uint32_t& as_u32(float& f) { return reinterpret_cast<uint32_t&>(f)
 // A SimpleTriangle (shape.h:81-109) keeps one vertex, the plane and the dual basis;
 // the other two vertices follow from m1.v1 = 1, m1.v2 = 0, m2.v2 = 1, m2.v1 = 0,
 // a.v1 = a.v2 = 0:  v1 = (m2 x a) / det,  v2 = (a x m1) / det,  det = m1 . (m2 x a).
-struct TriGeom { double v[3][3]; double c[3]; bool ok; uint32_t code; };
-
-static uint32_t spread3(uint32_t v)
-{
-    v &= 0x3ffu;
-    v = (v | (v << 16)) & 0x030000ffu; v = (v | (v << 8)) & 0x0300f00fu;
-    v = (v | (v << 4)) & 0x030c30c3u;  v = (v | (v << 2)) & 0x09249249u;
-    return v;
-}
+struct TriGeom { double v[3][3]; double c[3]; bool ok; };
 
 static void build_tree(const std::vector<rt_triangle>& tris, const rtd::SceneLayout& L, const uint32_t* node_pad,
                        uint32_t n_tri_pad, std::vector<Word>& blob)
 {
     const uint32_t n = (uint32_t)tris.size();
     std::vector<TriGeom> g(n);
-    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
     for (uint32_t i = 0; i < n; ++i) {
         const rt_triangle& t = tris[i];
         const double m1[3] = { t.m1[0], t.m1[1], t.m1[2] }, m2[3] = { t.m2[0], t.m2[1], t.m2[2] }, a[3] = { t.a[0], t.a[1], t.a[2] };
@@ -165,7 +156,6 @@ static void build_tree(const std::vector<rt_triangle>& tris, const rtd::SceneLay
             q.c[k] = (q.v[0][k] + q.v[1][k] + q.v[2][k]) / 3.0;
             if (!std::isfinite(q.v[1][k]) || !std::isfinite(q.v[2][k]) || !std::isfinite(q.v[0][k])) q.ok = false;
         }
-        if (q.ok) for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], q.c[k]); hi[k] = std::max(hi[k], q.c[k]); }
     }
     // Order the triangles by recursive median splits along the longest axis of their centroids'
     // extent (degenerate ones last).  Split points fall on multiples of the largest tree block
@@ -201,7 +191,6 @@ static void build_tree(const std::vector<rt_triangle>& tris, const rtd::SceneLay
         todo.push_back({ r.lo, r.lo + h });
         todo.push_back({ r.lo + h, r.hi });
     }
-    (void)lo; (void)hi; (void)spread3;
 
     const float nan = std::nanf("");
     // Sorted triangles, w0.w = index in the uploaded array; padding never hits (NaN plane).

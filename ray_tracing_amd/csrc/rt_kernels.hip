@@ -104,10 +104,15 @@ RT_DEV float sign_(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0
 RT_DEV float gmax(float x, float y) { return (x < y) ? y : x; }
 
 // ------------------------------------------------------------------- RNG
-// Counter-based: draw i of the path (seed, pixel, sample) is
-// hash32(key + i * 0x9E3779B9), key = hash32(hash32(seed_key ^ pixel) ^ sample).
-// It stands in for random() of RayTracing.glsl:44-51 (a hash of time,
-// invocation id and draw count) and for the mt19937 of src/utils.h:8-12.
+// Counter-based, one stream per path: the path (seed, pixel, sample) has the key
+// hash32(seed_key ^ pixel) + sample * 0x85EBCA6B, and its draws come in pairs — every event of a
+// path needs two — from ONE hashed word per pair: x = hash32(key + pair * 0x9E3779B9) gives
+// draw 2*pair from its top 24 bits and draw 2*pair + 1 from the top 24 bits of x * 0x2C1B3C6D.
+// Pair 0: sub-pixel jitter.  Bounce b: pair 1 + 2b (pair 2 + 2b is left to samplers that need four
+// draws).  It stands in for random() of RayTracing.glsl:44-51 (a hash of time, invocation id and
+// draw count) and for the mt19937 of src/utils.h:8-12.  The two steps differ so that no (sample,
+// pair) meets another one's hash input: s * 0x85EBCA6B + p * 0x9E3779B9 repeats only for sample
+// numbers 17 million apart (pairs up to 128 apart).
 RT_DEV uint32_t hash32(uint32_t x)
 {
     x ^= x >> 16; x *= 0x7feb352du;
@@ -115,12 +120,16 @@ RT_DEV uint32_t hash32(uint32_t x)
     x ^= x >> 16;
     return x;
 }
-RT_DEV float draw(uint32_t key, uint32_t index)
+constexpr uint32_t SAMPLE_STEP = 0x85ebca6bu;
+RT_DEV uint32_t path_key(uint32_t pixel_hash, uint32_t sample) { return pixel_hash + sample * SAMPLE_STEP; }
+RT_DEV void draw_pair(uint32_t key, uint32_t pair, float& a, float& b)
 {
-    return (float)(hash32(key + index * 0x9e3779b9u) >> 8) * 0x1p-24f;
+    const uint32_t x = hash32(key + pair * 0x9e3779b9u);
+    const uint32_t y = x * 0x2c1b3c6du;
+    a = (float)(x >> 8) * 0x1p-24f;
+    b = (float)(y >> 8) * 0x1p-24f;
 }
-// Draws 0,1: sub-pixel jitter.  Bounce b: draws 2+4b .. 5+4b.
-RT_DEV uint32_t bounce_draw(uint32_t bounce) { return 2u + 4u * bounce; }
+RT_DEV uint32_t bounce_pair(uint32_t bounce) { return 1u + 2u * bounce; }
 
 RT_DEV void sincos2pi(float u, float& c_out, float& s_out);
 
@@ -479,13 +488,13 @@ void trace_kernel(const TraceParams P,
             a = b = 0.0f;
             if (P.sample_mode == 0u) { a = glsl_random(state); b = glsl_random(state); }   // the grid modes draw nothing here
         }
-        else { a = draw(k, 0u); b = draw(k, 1u); }
+        else draw_pair(k, 0u, a, b);
     };
     V3 gs = v3(0, 0, 0);               // the shader stream's state (RNG_GLSL)
     uint32_t key = 0, bounce = 0;
     V3 o = v3(0, 0, 0), d = v3(0, 0, 1), thr = v3(1, 1, 1);
     if (alive) {
-        key = hash32(h1 ^ sample);
+        key = path_key(h1, sample);
         float j1, j2;
         start_draws(sample, key, gs, j1, j2);
         o = camera_origin(sample, j1, j2);
@@ -650,7 +659,7 @@ void trace_kernel(const TraceParams P,
             }
             ++sample;
             alive = sample < sample_end;
-            key = hash32(h1 ^ sample);
+            key += SAMPLE_STEP;                                            // path_key(h1, sample)
             if (STATS && alive) ++n_samples;
         }
         float u1, u2;
@@ -664,8 +673,7 @@ void trace_kernel(const TraceParams P,
             const bool uses = (ended && P.sample_mode == 0u) || (!ended && (diffuse || glass || (SEM == 0 && metal && fuzz != 0.0f)));
             gs = v3(uses ? g.x : gs.x, uses ? g.y : gs.y, uses ? g.z : gs.z);
         } else {
-            const uint32_t di = ended ? 0u : bounce_draw(bounce);
-            u1 = draw(key, di); u2 = draw(key, di + 1u);
+            draw_pair(key, ended ? 0u : bounce_pair(bounce), u1, u2);
         }
 
         if (ended) {
@@ -713,7 +721,7 @@ void trace_kernel(const TraceParams P,
                     }
                     ++sample;
                     alive = sample < sample_end;
-                    key = hash32(h1 ^ sample);
+                    key += SAMPLE_STEP;
                     if (STATS && alive) ++n_samples;
                     float j1, j2;
                     start_draws(sample, key, gs, j1, j2);

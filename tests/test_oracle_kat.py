@@ -19,13 +19,24 @@ def test_hash_and_draws(orc):
         assert orc.lib.orc_hash32(x) == lowbias32(x)
     key = orc.lib.orc_path_key(1, 77, 3)
     sk = lowbias32((1 & 0xffffffff) ^ lowbias32(0 ^ 0x85ebca6b))
-    assert key == lowbias32(lowbias32(sk ^ 77) ^ 3)
+    assert key == (lowbias32(sk ^ 77) + 3 * 0x85ebca6b) & 0xffffffff
     for i in range(16):
         u = orc.lib.orc_draw(key, i)
-        assert u == (lowbias32((key + i * 0x9e3779b9) & 0xffffffff) >> 8) / 2 ** 24
+        x = lowbias32((key + (i // 2) * 0x9e3779b9) & 0xffffffff)       # one hashed word per pair of draws
+        if i & 1:
+            x = (x * 0x2c1b3c6d) & 0xffffffff
+        assert u == (x >> 8) / 2 ** 24
         assert 0.0 <= u < 1.0
     us = np.array([orc.lib.orc_draw(lowbias32(k), i) for k in range(200) for i in range(50)])
     assert abs(us.mean() - 0.5) < 0.01 and abs(us.var() - 1 / 12) < 0.005
+    # The two draws of a pair share a hashed word: they must still fill the unit square evenly
+    # (a 16 x 16 histogram of 65 536 pairs: chi-square with 255 degrees of freedom) and be uncorrelated.
+    pairs = np.array([[orc.lib.orc_draw(lowbias32(k) + s * 0x85ebca6b, 2 * j), orc.lib.orc_draw(lowbias32(k) + s * 0x85ebca6b, 2 * j + 1)]
+                      for k in range(16) for s in range(256) for j in range(16)])
+    hist = np.histogram2d(pairs[:, 0], pairs[:, 1], bins=16, range=[[0, 1], [0, 1]])[0]
+    expected = len(pairs) / 256.0
+    assert ((hist - expected) ** 2 / expected).sum() < 340.0            # p ~ 3e-4 above this
+    assert abs(np.corrcoef(pairs[:, 0], pairs[:, 1])[0, 1]) < 0.02
     # streams of neighbouring pixels / samples are different
     assert len({orc.lib.orc_path_key(1, p, s) for p in range(64) for s in range(64)}) == 4096
 
