@@ -14,7 +14,7 @@ from collections import defaultdict
 
 def main():
     root = sys.argv[1]
-    needle = sys.argv[2] if len(sys.argv) > 2 else "trace_kernel<0, false, 0>"
+    needle = sys.argv[2] if len(sys.argv) > 2 else "trace_kernel<0, 0, 0>"
     out = {"kernel": needle}
     for f in glob.glob(os.path.join(root, "trace", "**", "*_kernel_stats.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
@@ -32,7 +32,29 @@ def main():
                 meta = {"vgpr": int(row["VGPR_Count"]), "sgpr": int(row["SGPR_Count"]), "lds": int(row["LDS_Block_Size"]),
                         "scratch": int(row["Scratch_Size"]), "grid": int(row["Grid_Size"]), "wg": int(row["Workgroup_Size"])}
     out["resources"] = meta
-    out["counters_per_launch"] = {k: sum(v) / len(v) for k, v in sorted(counters.items())}
+    c = out["counters_per_launch"] = {k: sum(v) / len(v) for k, v in sorted(counters.items())}
+    # Derived figures.  The SQ counters tick in quad-cycles and are summed over the chip; GRBM_GUI_ACTIVE is
+    # summed over the 8 XCDs.  1024 SIMDs (256 CUs x 4).
+    simds, xcds = 1024.0, 8.0
+    d = {}
+    if "GRBM_GUI_ACTIVE" in c:
+        cycles = c["GRBM_GUI_ACTIVE"] / xcds                      # shader cycles the launch lasted
+        d["kernel_cycles"] = round(cycles)
+        if "SQ_WAVE_CYCLES" in c:
+            d["mean_waves_per_simd"] = round(4.0 * c["SQ_WAVE_CYCLES"] / (cycles * simds), 2)                   # of 8 slots
+        if "SQ_INSTS_VALU" in c:
+            d["cycles_per_valu_instruction_per_simd"] = round(cycles * simds / c["SQ_INSTS_VALU"], 2)           # 2 = the pipe's best
+        if "SQ_ACTIVE_INST_VALU" in c:
+            d["valu_busy_percent_rocprof_formula"] = round(100.0 * 4.0 * c["SQ_ACTIVE_INST_VALU"] / (cycles * simds), 1)
+    if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
+        d["valu_lane_utilisation_percent"] = round(100.0 * c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 1)   # 100 = no divergence
+    if "SQ_WAIT_INST_ANY" in c and "SQ_WAVE_CYCLES" in c:
+        d["wave_time_waiting_for_issue_percent"] = round(100.0 * c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 1)
+    if "SQ_INSTS_VALU" in c and "SQ_INSTS_SALU" in c:
+        d["salu_per_valu_instruction"] = round(c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"], 3)
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        d["hbm_bytes_per_launch"] = round((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0)                   # gfx950: FETCH_SIZE tallies 128-B requests at 64 B
+    out["derived"] = d
     print(json.dumps(out, indent=1))
 
 

@@ -218,6 +218,7 @@ RT_DEV V3 hemisphere_glsl(V3 n, float u1, float u2)
 //   CPU tracer: 0.001 < t (double against widened float: true exactly from
 //               0.001f on) and t < FLT_MAX.
 //   Shader:     0.0001 < t < 1000.
+// `far` itself is outside: the running best starts one float below it.
 template <int SEM> struct Window;
 template <> struct Window<0> { static constexpr uint32_t tmin = 0x3a83126fu, far = 0x7f7fffffu; };   // 0.001f, FLT_MAX
 template <> struct Window<1> { static constexpr uint32_t tmin = 0x38d1b718u, far = 0x447a0000u; };   // next above 0.0001f, 1000.0f
@@ -530,7 +531,9 @@ void trace_kernel(const TraceParams P,
         //      and every replacement needs a strictly smaller distance, so a
         //      triangle wins only when strictly closer than the closest shape
         //      (glsl:271) and the first of equal distances stays.
-        Best best = { Window<SEM>::far - Window<SEM>::tmin, NONE };
+        // "Nothing yet" = (last accepted distance, NONE): a hit at that very distance still wins by its index,
+        // anything from `far` on loses (t < FLT_MAX, scene.h:237; distance < 1000, glsl:212).
+        Best best = { Window<SEM>::far - 1u - Window<SEM>::tmin, NONE };
         for (uint32_t c = 0; c < n_chunks; ++c) {
             const float4 s0 = sph[4u * c], s1 = sph[4u * c + 1u], s2 = sph[4u * c + 2u], s3 = sph[4u * c + 3u];
             const float4 ids = sid[c];

@@ -347,3 +347,32 @@ def test_sliced_sample_ranges(rta, orc):
             assert st["work_units"] == n_tiles
     finally:
         rt.close()
+
+
+def _axis_ray_scene(rta, sphere_z, semantics):
+    """A 1x1 frame whose one grid sample leaves (0, 0, -7) along exactly (0, 0, -1) (the normalisation of
+    (0, 0, -7) is exact), and one emissive unit sphere centred on the ray at z = sphere_z."""
+    from ray_tracing_amd import host, _abi
+    cam = np.zeros(21, dtype=np.float32)
+    cam[4:7] = (0, 0, -1); cam[8:11] = (0, 0, -7); cam[12:15] = (0, 1, 0); cam[16:19] = (1, 0, 0); cam[19] = 1.0 / 64
+    shapes = host.pack([host.Circle((0, 0, sphere_z), 1.0, host.Light((1, 1, 1)))], _abi.SHAPE_DTYPE)
+    return rta.scenes.SceneConfig("far_edge", shapes, np.zeros(0, dtype=_abi.TRIANGLE_DTYPE), cam, 1, 1, 1, 2, semantics,
+                                  sample_mode=_abi.SAMPLE_GRID)
+
+
+def test_far_edge_of_the_window_is_exclusive(rta, orc):
+    """RayTracing.glsl:212 accepts distance < 1000 only.  With the sphere at z = -1008 the hit distance is exactly
+    1000.0f (oc.d = -1001, disc = 1): a miss; one float nearer it is a hit."""
+    far = _axis_ray_scene(rta, -1008.0, 1)
+    near = _axis_ray_scene(rta, float(np.nextafter(np.float32(-1008.0), np.float32(0))), 1)
+    assert orc.hit_sphere((0.0, 0.0, -1008.0), 1.0, (0.0, 0.0, -7.0), (0.0, 0.0, -1.0)) == 1000.0
+    for cfg, want in ((far, -1), (near, 0)):
+        rt = rta.scenes.make_renderer(cfg)
+        try:
+            hit, _ = rt.traceDebug(1, 1, 2, cfg.seed, 0, grid_n=1)
+            ohit, _ = orc.trace(cfg.shapes, cfg.triangles, cfg.camera, oracle_params(orc, cfg, grid_n=1), 0)
+            assert int(ohit.ravel()[0]) == want
+            np.testing.assert_array_equal(hit, ohit)
+        finally:
+            rt.close()
+
