@@ -376,3 +376,41 @@ def test_far_edge_of_the_window_is_exclusive(rta, orc):
         finally:
             rt.close()
 
+
+@pytest.mark.parametrize("n_tris", [1, 5, 101, 290])
+def test_triangle_count_not_a_multiple_of_the_leaf(rta, orc, n_tris):
+    """Both meshes of the reference happen to hold a multiple of four triangles (292, 4 968); the tree's
+    leaves hold four, so other counts exercise its padding."""
+    cfg = rta.scenes.config3(width=96, height=54, spp=4, max_depth=6)
+    cfg.triangles = cfg.triangles[:n_tris].copy()
+    check_config(rta, orc, cfg)
+
+
+def test_ties_keep_the_first_in_upload_order(rta, orc):
+    """Coincident primitives: the closest-hit scans replace the best only by a strictly smaller distance
+    (scene.h:237, RayTracing.glsl:212,226), so of equal distances the first uploaded wins — here every sphere,
+    box and triangle of the mesh scene exists twice, the copy in another colour, and the triangles (which the
+    library reorders for its tree) also in reversed order."""
+    cfg = rta.scenes.config3(width=96, height=54, spp=4, max_depth=6)
+    twin = cfg.shapes.copy()
+    twin["material"]["color"] = 1.0 - twin["material"]["color"]
+    cfg.shapes = np.concatenate([cfg.shapes, twin])
+    cfg.triangles = np.concatenate([cfg.triangles, cfg.triangles[::-1]])
+    cfg.triangle_colors = np.concatenate([np.tile(np.float32([[0.9, 0.2, 0.1]]), (292, 1)), np.tile(np.float32([[0.1, 0.2, 0.9]]), (292, 1))])
+    st = check_config(rta, orc, cfg)
+    hit, _ = (lambda rt: (rt.traceDebug(cfg.width, cfg.height, cfg.max_depth, cfg.seed, 0), rt.close())[0])(rta.scenes.make_renderer(cfg))
+    first = hit[..., 0]
+    assert (first < 9).sum() > 0 and ((first >= 18) & (first < 18 + 292)).sum() > 0      # shapes and triangles were hit ...
+    assert ((first >= 9) & (first < 18)).sum() == 0 and (first >= 18 + 292).sum() == 0   # ... and never a copy
+    assert st["segments"] > 0
+
+
+def test_degenerate_triangles_do_not_break_the_tree(rta, orc):
+    """Zero-area triangles (their plane and dual basis are NaN or infinite, shape.h:93-101) can never be hit, and the
+    bounds over them must not hide their neighbours."""
+    from ray_tracing_amd import host
+    cfg = rta.scenes.config3(width=96, height=54, spp=4, max_depth=6)
+    bad = host.pack([host.SimpleTriangle((0, 1, -2), (0, 1, -2), (1, 1, -2)), host.SimpleTriangle((1, 1, 1), (2, 2, 2), (3, 3, 3))], cfg.triangles.dtype)
+    cfg.triangles = np.concatenate([cfg.triangles[:50], bad[:1], cfg.triangles[50:200], bad[1:], cfg.triangles[200:]])
+    check_config(rta, orc, cfg)
+
