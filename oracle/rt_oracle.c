@@ -94,7 +94,7 @@ static inline float gmax(float x, float y) { return (x < y) ? y : x; }
  * stream per (seed, pixel, sample), indexed by draw number.  The path has the key
  * hash32(seed_key ^ pixel) + sample * 0x85EBCA6B; its draws come in pairs (every event of a path
  * needs two) from one hashed word per pair: x = hash32(key + (i / 2) * 0x9E3779B9) gives draw i,
- * i even, from its top 24 bits and draw i + 1 from the top 24 bits of x * 0x2C1B3C6D.  The two
+ * i even, from its top 24 bits and draw i + 1 from the top 24 bits of x * 0xADB4A92D.  The two
  * steps differ so that no (sample, pair) meets another one's hash input: s * 0x85EBCA6B +
  * p * 0x9E3779B9 repeats only for sample numbers 17 million apart (pairs up to 128 apart). */
 uint32_t orc_hash32(uint32_t x)
@@ -119,7 +119,7 @@ uint32_t orc_path_key(uint64_t seed, uint32_t pixel_index, uint32_t sample)
 float orc_draw(uint32_t key, uint32_t index)
 {
     uint32_t x = orc_hash32(key + (index >> 1) * 0x9e3779b9u);
-    if (index & 1u) x *= 0x2c1b3c6du;
+    if (index & 1u) x *= 0xadb4a92du;
     return (float)(x >> 8) * 0x1p-24f;
 }
 

@@ -107,7 +107,9 @@ RT_DEV float gmax(float x, float y) { return (x < y) ? y : x; }
 // Counter-based, one stream per path: the path (seed, pixel, sample) has the key
 // hash32(seed_key ^ pixel) + sample * 0x85EBCA6B, and its draws come in pairs — every event of a
 // path needs two — from ONE hashed word per pair: x = hash32(key + pair * 0x9E3779B9) gives
-// draw 2*pair from its top 24 bits and draw 2*pair + 1 from the top 24 bits of x * 0x2C1B3C6D.
+// draw 2*pair from its top 24 bits and draw 2*pair + 1 from the top 24 bits of x * 0xADB4A92D (as a
+// pair the two lie on the lattice of that multiplier modulo 2^32, whose shortest vector is 0.98 of the best
+// possible: the 2^32 points of a pair are spread evenly over the unit square).
 // Pair 0: sub-pixel jitter.  Bounce b: pair 1 + 2b (pair 2 + 2b is left to samplers that need four
 // draws).  It stands in for random() of RayTracing.glsl:44-51 (a hash of time, invocation id and
 // draw count) and for the mt19937 of src/utils.h:8-12.  The two steps differ so that no (sample,
@@ -125,7 +127,7 @@ RT_DEV uint32_t path_key(uint32_t pixel_hash, uint32_t sample) { return pixel_ha
 RT_DEV void draw_pair(uint32_t key, uint32_t pair, float& a, float& b)
 {
     const uint32_t x = hash32(key + pair * 0x9e3779b9u);
-    const uint32_t y = x * 0x2c1b3c6du;
+    const uint32_t y = x * 0xadb4a92du;
     a = (float)(x >> 8) * 0x1p-24f;
     b = (float)(y >> 8) * 0x1p-24f;
 }
@@ -642,7 +644,8 @@ void trace_kernel(const TraceParams P,
         V3 v = v3(0, 0, 1);                                           // new direction before normalisation
         const bool diffuse = type == 1u, metal = type == 2u, glass = HAS_GLASS && type == 3u;
         if (STATS) { n_diffuse += diffuse ? 1u : 0u; n_specular += (metal || glass) ? 1u : 0u; }
-        if (type == 0u) color = thr * att;                            // LightSource::emit / glsl:278-280
+        const V3 ta = thr * att;                                      // a light returns it, a bounce carries it on
+        if (type == 0u) color = ta;                                   // LightSource::emit / glsl:278-280
         else if (type == 100u) color = (SEM == 0) ? thr * n : n;      // glsl:248-252
         else if (!diffuse && !metal && !glass && type != NONE) color = (SEM == 0) ? v3(0, 0, 0) : thr;   // glsl:253,282-284
         else if ((diffuse || metal || glass) && !last) ended = false;
@@ -687,7 +690,7 @@ void trace_kernel(const TraceParams P,
         } else {
             ++bounce;
             o = p;
-            thr = thr * att;                                          // scene.h:56 (0.6*albedo, formed at upload), :79; glsl:241,246,275
+            thr = ta;                                                 // scene.h:56 (0.6*albedo, formed at upload), :79; glsl:241,246,275
             if (diffuse) {
                 if (SEM == 0) {
                     v = madd(1.0001f, n, unit_vector(u1, u2));        // Lambertian::scatter, scene.h:51-58; utils.h:48-50

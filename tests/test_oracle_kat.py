@@ -24,7 +24,7 @@ def test_hash_and_draws(orc):
         u = orc.lib.orc_draw(key, i)
         x = lowbias32((key + (i // 2) * 0x9e3779b9) & 0xffffffff)       # one hashed word per pair of draws
         if i & 1:
-            x = (x * 0x2c1b3c6d) & 0xffffffff
+            x = (x * 0xadb4a92d) & 0xffffffff
         assert u == (x >> 8) / 2 ** 24
         assert 0.0 <= u < 1.0
     us = np.array([orc.lib.orc_draw(lowbias32(k), i) for k in range(200) for i in range(50)])
