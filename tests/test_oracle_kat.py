@@ -405,3 +405,35 @@ def test_dielectric_obeys_snell_and_schlick(orc):
     assert orc.glass_direction(n, d0, 1.5, r0 * 1.01)[2] < 0            # above: refracted
     graze = (float(np.sin(np.radians(89.9))), 0.0, float(-np.cos(np.radians(89.9))))
     assert orc.glass_direction(n, graze, 1.5, 0.98)[2] > 0              # reflectance -> 1 at grazing incidence
+
+
+def test_floor_under_a_ceiling_light_has_the_closed_form_radiance(rta, orc):
+    """A diffuse floor under an emitter that fills all of its sky but a rim at the horizon: one bounce reaches the
+    light or nothing, so a floor pixel converges to attenuation * Le * P(bounce reaches the light).
+      Shader rules (RayTracing.glsl:64-80,241): the bounce's component along the normal is uniform in [0,1); the
+        ceiling (bottom face of a 1000-box, 10 above the floor, half-width 500) is reached when it exceeds
+        10/sqrt(10^2+500^2)-ish = 0.02 -> P = 0.98; attenuation = albedo.
+      CPU rules (scene.h:51-58, utils.h:45-50): cosine-weighted; a sphere of radius 1000 whose lowest point is 10
+        above the floor fills the cone sin(alpha) = 1000/1010 -> P = sin^2(alpha) = 0.9803; attenuation = 0.6 * albedo."""
+    L, Li = rta.Lambertian, rta.Light
+    no_tris = np.zeros(0, rta.TRIANGLE_DTYPE)
+    # shader rules: boxes.  albedo 0.5, Le 2 -> every lit sample is exactly 1.0 (255 after quantisation)
+    shapes = rta.pack([rta.Box((0, -50, 0), (100, 1, 1), L((0.5, 0.5, 0.5))), rta.Box((0, 510, 0), (1000, 1, 1), Li((2, 2, 2)))], rta.SHAPE_DTYPE)
+    cam = rta.Camera(64, 64, 1.0, (0, 1, 0)).data
+    p = orc.params(64, 64, 64, 3, semantics=1)
+    acc, _ = orc.render(shapes, no_tris, cam, p)
+    img = orc.resolve(acc, 64, 1, flip_rows=False)
+    first = orc.trace(shapes, no_tris, cam, p, 0)[0][:, :, 0]
+    floor = (first == 0) & (np.arange(64)[:, None] >= 44)         # steep rays: every sample of the pixel lands near the camera
+    assert floor.sum() > 1000
+    assert abs(img[floor][:, 0].mean() - 0.98) < 0.004
+    # CPU rules: spheres.  0.6 * 0.5 * Le 2 = 0.6 per lit sample
+    shapes = rta.pack([rta.Circle((0, -100, 0), 100.0, L((0.5, 0.5, 0.5))), rta.Circle((0, 1010, 0), 1000.0, Li((2, 2, 2)))], rta.SHAPE_DTYPE)
+    p = orc.params(64, 64, 64, 3, semantics=0)
+    acc, _ = orc.render(shapes, no_tris, cam, p)
+    img = orc.resolve(acc, 64, 0, flip_rows=False)
+    first = orc.trace(shapes, no_tris, cam, p, 0)[0][:, :, 0]
+    near = (first == 0) & (np.arange(64)[:, None] >= 48)          # steep rays: floor points close to the sphere's top
+    assert near.sum() > 500
+    assert abs(img[near][:, 0].mean() - 0.6 * (1000.0 / 1010.0) ** 2) < 0.006
+
