@@ -49,7 +49,7 @@ def check_config(rta, orc, cfg, trace_samples=(0,), grid_n=0):
 
 
 def test_config1_cpu_sphere_scene(rta, orc):
-    """BASELINE config 1 at full size: 512x512, 16 spp, depth 4."""
+    """The CPU-runnable configuration at full size: 512x512, 16 spp, depth 4."""
     st = check_config(rta, orc, rta.scenes.config1(), trace_samples=(0, 7, 15))
     assert st["samples"] == 512 * 512 * 16
 
