@@ -31,6 +31,7 @@ F_BOUND = 20                          # one ray / bounding-sphere test of the tr
 F_CAMERA, F_DIFFUSE, F_SPECULAR, F_TERMINAL = 25 + 2 * 11, 90, 30, 3
 PEAK_FP32_VECTOR_TFLOPS = 157.3       # 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
+PEAK_CLOCK_HZ, N_SIMD = 2.4e9, 1024
 
 
 def algorithmic_flops(st, executed=True):
@@ -217,15 +218,25 @@ def main():
         value = samples_per_step / (elapsed / args.steps) / 1e6
         flops = algorithmic_flops(stats)
         achieved = flops / (kernel_ms * 1e-3) / 1e12
-        traffic = None
+        # Counters of the same launch from the committed rocprofv3 passes (profiles/traffic.json): HBM bytes, and
+        # the vector instructions issued, which price the launch in issue slots of the vector pipe.
+        traffic, issue = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                key = f"{args.config}_{cfg.width}x{cfg.height}_{shard.spp}spp"
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath)).get(f"{args.config}_{cfg.width}x{cfg.height}_{shard.spp}spp", {}) if not args.mesh else {}
+                traffic = tj.get("hbm_bytes_per_launch")
+                if tj.get("valu_instructions_per_launch"):
+                    n_inst = tj["valu_instructions_per_launch"]
+                    cyc = kernel_ms * 1e-3 * PEAK_CLOCK_HZ * N_SIMD / n_inst
+                    issue = {"valu_instructions_per_launch": n_inst, "cycles_per_instruction_per_simd": round(cyc, 3),
+                             "best_cycles_per_instruction": 2.0, "issue_slots_used": round(2.0 / cyc, 4),
+                             "lanes_enabled_percent": tj.get("valu_lane_utilisation_percent"),
+                             "mean_waves_per_simd": tj.get("mean_waves_per_simd"), "source": tj.get("source"),
+                             "note": "1024 SIMDs at 2.4 GHz; a wave64 fp32 instruction issues in 2 cycles at best, compares / selects / "
+                                     "conversions / integer multiplies in 4, sqrt / rcp in 8"}
             except Exception:
-                traffic = None
+                traffic, issue = None, None
         info = rta.device_info(local_rank)
         result = {
             "metric": "Msamples/sec at 1080p", "value": round(value, 2), "unit": "Msamples/s",
@@ -244,6 +255,7 @@ def main():
                          "algorithmic_flops_per_launch": flops,
                          "exhaustive_scan_flops_per_launch": algorithmic_flops(stats, executed=False),
                          "algorithmic_hbm_bytes_per_launch": cfg.width * cfg.height * 32,
+                         "valu_issue": issue,
                          "note": "fp32 vector (VALU) bound: no dense contraction, no MFMA; HBM traffic is the framebuffer only"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -25,7 +25,7 @@ namespace rtd {
 hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams& P, const void* blob,
                         uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm,
                         const uint32_t* tile_order, uint32_t* tile_cost, uint32_t n_workgroups);
-hipError_t launch_tile_plan(hipStream_t stream, uint32_t* cost, uint32_t* work, uint32_t n, uint32_t extra, uint32_t max_slices, float share);
+hipError_t launch_tile_plan(hipStream_t stream, uint32_t* cost, uint32_t* work, uint32_t n, uint32_t extra, uint32_t max_slices, float share, float early_share);
 hipError_t launch_trace_fill(hipStream_t stream, int32_t* hit, uint32_t* mat, size_t n);
 hipError_t launch_resolve(int sem, hipStream_t stream, const uint32_t* accum, float* out, uint32_t w, uint32_t h,
                           uint32_t samples, int gamma_sqrt, int flip_rows);
@@ -644,7 +644,10 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         // A tile is cut when it costs more than a quarter of an even share (measured: 0.5 -> 48 ms, 0.35 -> 45,
         // 0.25 -> 41, 0.125 -> 41 on the 292-triangle mesh scene; no effect on scenes without expensive tiles).
         const float share = 0.25f;
-        RT_HIP(ctx, rtd::launch_tile_plan(ctx->stream, ctx->d_tile_cost, ctx->d_tile_order, n_tiles, extra, max_slices, share));
+        // Uncut tiles above half the cutting threshold are as long as the slices and follow them directly (measured on the
+        // same scene: 41.0 ms without, 39.1-40.3 ms with; putting them before the slices instead: the same).
+        const float early_share = 0.5f;
+        RT_HIP(ctx, rtd::launch_tile_plan(ctx->stream, ctx->d_tile_cost, ctx->d_tile_order, n_tiles, extra, max_slices, share, early_share));
         ctx->order_tiles_x = P.tiles_x; ctx->order_tiles_y = P.tiles_y;
         ctx->plan_units = n_tiles + extra;
     }

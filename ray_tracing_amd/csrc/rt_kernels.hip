@@ -794,13 +794,14 @@ void trace_kernel(const TraceParams P,
 //     evenly (sum of costs / 2048: four waves per tile, 8192 slots) is cut into up to max_slices
 //     slices; the threshold is raised until the additional entries fit into `extra`.  These go first.
 //   * Tiles that cost more than twice the mean but are not cut (max_slices = 1: float sums, whose
-//     order of addition is part of the result) go next.
+//     order of addition is part of the result) go next; when tiles are being cut, so do the uncut
+//     ones above early_share of the cutting threshold.
 //   * All other tiles keep the built-in order (bottom rows first), which interleaves long and short
 //     tiles on every CU — measured faster than a full longest-first sort, whose tail of short tiles
 //     is all start-up latency.
 // One workgroup.
 __global__ __launch_bounds__(1024)
-void tile_plan_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ work, uint32_t n, uint32_t extra, uint32_t max_slices, float share)
+void tile_plan_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ work, uint32_t n, uint32_t extra, uint32_t max_slices, float share, float early_share)
 {
     __shared__ unsigned long long scan[1024];
     __shared__ unsigned long long total;
@@ -814,7 +815,7 @@ void tile_plan_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ work, 
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
     if ((tid & 63u) == 0u) atomicAdd(&total, sum);
     __syncthreads();
-    const uint32_t limit = (uint32_t)min(0xffffffffull, 2ull * total / n);      // twice the mean
+    uint32_t limit = (uint32_t)min(0xffffffffull, 2ull * total / n);            // twice the mean
     // Position j of the built-in order is tile n-1-j; thread t owns positions [t*chunk, (t+1)*chunk).
     const uint32_t chunk = (n + 1023u) / 1024u;
     const uint32_t j0 = min(n, tid * chunk), j1 = min(n, j0 + chunk);
@@ -841,6 +842,10 @@ void tile_plan_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ work, 
     } else {
         max_slices = 1u;
     }
+
+    // With cutting on, the longest pieces of work left are the tiles just under the cutting threshold; those above
+    // `early_share` of it follow the slices directly, or they would start late and end the launch alone.
+    if (max_slices > 1u && n_extra > 0u) limit = min(limit, (uint32_t)fminf(target * early_share, 4294967040.0f));
 
     // Entries per class, packed 21 bits each: cut tiles' slices, uncut expensive tiles, the rest.
     unsigned long long mine = 0ull;
@@ -947,9 +952,9 @@ static hipError_t launch_one(dim3 grid, size_t lds_bytes, hipStream_t stream, co
     return hipGetLastError();
 }
 
-hipError_t launch_tile_plan(hipStream_t stream, uint32_t* cost, uint32_t* work, uint32_t n, uint32_t extra, uint32_t max_slices, float share)
+hipError_t launch_tile_plan(hipStream_t stream, uint32_t* cost, uint32_t* work, uint32_t n, uint32_t extra, uint32_t max_slices, float share, float early_share)
 {
-    hipLaunchKernelGGL(tile_plan_kernel, dim3(1), dim3(1024), 0, stream, cost, work, n, extra, max_slices, share);
+    hipLaunchKernelGGL(tile_plan_kernel, dim3(1), dim3(1024), 0, stream, cost, work, n, extra, max_slices, share, early_share);
     return hipGetLastError();
 }
 
