@@ -8,9 +8,10 @@ namespace rtd {
 // ("blob") in device memory, built at upload time from the reference's
 // 144-byte Shape (src/gpu_version/shape.h:44-54) and 64-byte SimpleTriangle
 // (shape.h:103-108) arrays.  Every workgroup copies the first `lds_words`
-// words into LDS before tracing and addresses them there; what does not fit
-// (a mesh larger than the LDS budget) is read from the blob in global memory
-// with wave-uniform addresses.
+// words into LDS before tracing and addresses them there: the whole blob, or
+// — when a mesh makes it larger than the LDS budget — the shapes only, the
+// mesh and its tree then being read from the blob in global memory with
+// wave-uniform addresses.
 //
 //   rec  [4 * n_shapes]   per shape, by the shape's index in the uploaded array:
 //                           word 0: centre.xyz, scale (Circle: radius, Box: side)
@@ -81,7 +82,7 @@ constexpr int BLOCK = 256;
 // LDS a workgroup may use for the staged scene.  8 workgroups of 4 waves fill a
 // CU's 32 wave slots; 160 KiB / 8 = 20 KiB each keeps that occupancy.  Scenes
 // up to LDS_MAX_BYTES are still staged (fewer workgroups per CU); beyond it the
-// triangles stay in global memory.
+// triangles and their tree stay in global memory.
 constexpr uint32_t LDS_FULL_OCCUPANCY_BYTES = 20u * 1024u;
 constexpr uint32_t LDS_MAX_BYTES = 64u * 1024u;
 

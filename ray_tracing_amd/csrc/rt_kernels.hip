@@ -513,10 +513,13 @@ void trace_kernel(const TraceParams P,
     const float4* const cub = lds + L.cub_off;
     const float4* const tri = TRI_GLOBAL ? blob + L.tri_off : lds + L.tri_off;
     const uint32_t* const slot_of = reinterpret_cast<const uint32_t*>(TRI_GLOBAL ? blob + L.inv_off : lds + L.inv_off);
-    const float4* const node0 = lds + L.node_off[0];
-    const float4* const node1 = lds + L.node_off[1];
-    const float4* const node2 = lds + L.node_off[2];
-    const float4* const node3 = lds + L.node_off[3];
+    // The tree over a staged mesh is staged with it; that of a mesh in global memory is read from there too
+    // (measured on the 4 968-triangle mesh: where its tree lives makes no difference, 120-123 ms either way).
+    const float4* const nodes = TRI_GLOBAL ? blob : lds;
+    const float4* const node0 = nodes + L.node_off[0];
+    const float4* const node1 = nodes + L.node_off[1];
+    const float4* const node2 = nodes + L.node_off[2];
+    const float4* const node3 = nodes + L.node_off[3];
     const uint32_t n_chunks = L.n_sph_pad >> 2, n_box = L.n_box, n_shapes = L.n_shapes;
     // The bounds assume a unit direction; the as-written fuzzy metal leaves it unnormalised.
     const bool cull = (P.flags & 1u) == 0u;

@@ -414,3 +414,29 @@ def test_degenerate_triangles_do_not_break_the_tree(rta, orc):
     cfg.triangles = np.concatenate([cfg.triangles[:50], bad[:1], cfg.triangles[50:200], bad[1:], cfg.triangles[200:]])
     check_config(rta, orc, cfg)
 
+
+def _wavy_sheet(n):
+    """2 * n * n triangles: a rippled sheet standing behind the spheres of the mesh scene."""
+    from ray_tracing_amd import host, _abi
+    u = np.linspace(-3.0, 4.0, n + 1, dtype=np.float32)
+    v = np.linspace(0.05, 4.0, n + 1, dtype=np.float32)
+    x, y = np.meshgrid(u, v)
+    z = (-7.0 + 0.3 * np.sin(3.0 * x) * np.cos(2.0 * y)).astype(np.float32)
+    pts = np.stack([x, y, z], axis=-1)
+    tris = []
+    for j in range(n):
+        for i in range(n):
+            a, b, c, d = pts[j, i], pts[j, i + 1], pts[j + 1, i], pts[j + 1, i + 1]
+            tris.append(host.SimpleTriangle(a, b, c))
+            tris.append(host.SimpleTriangle(b, d, c))
+    return host.pack(tris, _abi.TRIANGLE_DTYPE)
+
+
+def test_mesh_larger_than_the_lds_stage(rta, orc):
+    """20 000 triangles: neither the mesh (1.3 MB) nor its tree (91 KB) fits the 64 KB a workgroup may stage, so
+    both are read from global memory; the result is the exhaustive scan's all the same."""
+    cfg = rta.scenes.config3(width=64, height=36, spp=2, max_depth=4)
+    cfg.triangles = _wavy_sheet(100)
+    assert len(cfg.triangles) == 20000
+    st = check_config(rta, orc, cfg)
+    assert st["triangle_tests"] == st["segments"] * 20000
