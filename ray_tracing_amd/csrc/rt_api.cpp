@@ -279,9 +279,10 @@ static int build_blob(rt_ctx* ctx)
     L.tri_off = L.inv_off + (n_tris + 3u) / 4u;
     L.total_words = L.tri_off + 4u * n_tri_pad;
     const bool colors = !ctx->tri_colors.empty() && ctx->tri_colors.size() == 3u * (size_t)n_tris;
-    if ((size_t)L.node_off[rtd::TREE_LEVELS - 1u] * 16u > rtd::LDS_MAX_BYTES)
+    const uint32_t wave_words = n_tris ? rtd::LDS_WAVE_WORDS_PER_GROUP : 0u;       // queues and slots of the triangle tests
+    if ((size_t)(L.node_off[rtd::TREE_LEVELS - 1u] + wave_words) * 16u > rtd::LDS_MAX_BYTES)
         return fail(ctx, RT_ERR_INVALID_ARG, "scene: %u shapes need more than the %u-byte LDS stage", n_shapes, rtd::LDS_MAX_BYTES);
-    if ((size_t)L.total_words * 16u <= rtd::LDS_MAX_BYTES) { L.lds_words = L.total_words; L.tri_in_lds = 1; }
+    if ((size_t)(L.total_words + wave_words) * 16u <= rtd::LDS_MAX_BYTES) { L.lds_words = L.total_words; L.tri_in_lds = 1; }
     else { L.lds_words = L.node_off[rtd::TREE_LEVELS - 1u]; L.tri_in_lds = 0; }     // the mesh and its tree stay in global memory
     // Per-triangle albedo: read only at a hit, so it stays in global memory behind everything else.
     if (colors) { L.tcol_off = L.total_words; L.total_words += n_tris; }

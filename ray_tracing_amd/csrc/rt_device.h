@@ -85,5 +85,10 @@ constexpr int BLOCK = 256;
 // triangles and their tree stay in global memory.
 constexpr uint32_t LDS_FULL_OCCUPANCY_BYTES = 20u * 1024u;
 constexpr uint32_t LDS_MAX_BYTES = 64u * 1024u;
+// With triangles in the scene every wave of a workgroup owns, behind the staged scene, a queue of (lane, leaf)
+// pairs (QUEUE_ENTRIES x 4 bytes) and one 8-byte slot per lane for the closest triangle found.
+constexpr uint32_t QUEUE_ENTRIES = 128u;
+constexpr uint32_t WAVE_LDS_WORDS = (QUEUE_ENTRIES * 4u + 64u * 8u) / 16u;
+constexpr uint32_t LDS_WAVE_WORDS_PER_GROUP = (BLOCK / 64) * WAVE_LDS_WORDS;
 
 }  // namespace rtd

@@ -326,8 +326,9 @@ RT_DEV float hit_cube(float4 r0, float4 r1, float4 r2, V3 o, V3 d, V3& in_point)
 // hitTriangle, RayTracing.glsl:179-194, on the four words of a SimpleTriangle
 // (w0.w carries the triangle's index in the uploaded array).  The early return
 // for k < 0 (:182-184) is left to the window test, which rejects every negative k.
+// -> does the ray cross the triangle; `key` = its window key (any value outside the window loses later), `id` = its hit index.
 template <int SEM>
-RT_DEV void test_triangle(float4 w0, float4 w1, float4 w2, float4 w3, uint32_t n_shapes, V3 o, V3 d, Best& best)
+RT_DEV bool triangle_candidate(float4 w0, float4 w1, float4 w2, float4 w3, uint32_t n_shapes, V3 o, V3 d, uint32_t& key, uint32_t& id)
 {
     V3 a = xyz(w1);
     float k = (w1.w - dot(a, o)) * rcp_nr(dot(a, d));
@@ -335,8 +336,16 @@ RT_DEV void test_triangle(float4 w0, float4 w1, float4 w2, float4 w3, uint32_t n
     V3 q = v3(p.x - w0.x, p.y - w0.y, p.z - w0.z);
     float x = dot(q, xyz(w2));
     float y = dot(q, xyz(w3));
-    take_if_closer(best, __float_as_uint(k) - Window<SEM>::tmin, n_shapes + __float_as_uint(w0.w),
-                   x > 0.0f && y > 0.0f && (x + y) < 1.0f);
+    key = __float_as_uint(k) - Window<SEM>::tmin;
+    id = n_shapes + __float_as_uint(w0.w);
+    return x > 0.0f && y > 0.0f && (x + y) < 1.0f;
+}
+template <int SEM>
+RT_DEV void test_triangle(float4 w0, float4 w1, float4 w2, float4 w3, uint32_t n_shapes, V3 o, V3 d, Best& best)
+{
+    uint32_t key, id;
+    const bool inside = triangle_candidate<SEM>(w0, w1, w2, w3, n_shapes, o, d, key, id);
+    take_if_closer(best, key, id, inside);
 }
 
 // Can the ray touch the bounding sphere nb = {centre.xyz, R}?  It does when its line passes
@@ -368,10 +377,10 @@ RT_DEV uint32_t quantise(float c)
 // -------------------------------------------------------------- the tracer
 // SEM 0: rules of src/cpu_version (rayTracer.h:110-132, scene.h:39-109).
 // SEM 1: rules of RayTracing.glsl:233-288.
-// GEO bit 0: the triangles did not fit into LDS and are read from the blob in
-// global memory; bit 1: the scene holds cubes of the CPU tracer, dielectric
+// GEO bits 0-1: 0 no triangles (the instance has no traversal code), 1 triangles staged in LDS, 2 triangles
+// and their tree read from the blob in global memory; bit 2: the scene holds cubes of the CPU tracer, dielectric
 // materials or a colour per triangle (kept out of the other instances, whose registers and issue slots they
-// would cost: 12 % on the four-sphere scene); bit 2: draws come from the
+// would cost: 12 % on the four-sphere scene); bit 3: draws come from the
 // shader's own random() instead of the counter hash.  MODE 0: render.  MODE 1: render and count work.  MODE 2:
 // follow one sample, record hit and material ids, leave the accumulator alone.
 //
@@ -393,7 +402,7 @@ void trace_kernel(const TraceParams P,
 {
     constexpr bool STATS = MODE == 1, TRACE = MODE == 2;
     constexpr bool COST_CLOCK = RT_COST_CLOCK != 0;        // a tile's cost: shader clocks of its slowest wave, not loop iterations
-    constexpr bool TRI_GLOBAL = (GEO & 1) != 0, HAS_CUBE = SEM == 0 && (GEO & 2) != 0, HAS_GLASS = (GEO & 2) != 0, HAS_TCOL = (GEO & 2) != 0, RNG_GLSL = (GEO & 4) != 0;
+    constexpr bool HAS_TRI = (GEO & 3) != 0, TRI_GLOBAL = (GEO & 3) == 2, HAS_CUBE = SEM == 0 && (GEO & 4) != 0, HAS_GLASS = (GEO & 4) != 0, HAS_TCOL = (GEO & 4) != 0, RNG_GLSL = (GEO & 8) != 0;
     extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -521,6 +530,12 @@ void trace_kernel(const TraceParams P,
     const float4* const node2 = nodes + L.node_off[2];
     const float4* const node3 = nodes + L.node_off[3];
     const uint32_t n_chunks = L.n_sph_pad >> 2, n_box = L.n_box, n_shapes = L.n_shapes;
+    // Behind the staged scene every wave has a queue of (lane, leaf) pairs waiting for their triangle tests and
+    // one slot per lane for the closest triangle those tests found.
+    uint32_t* const queue = reinterpret_cast<uint32_t*>(lds + L.lds_words + (tid >> 6) * WAVE_LDS_WORDS);
+    unsigned long long* const found = reinterpret_cast<unsigned long long*>(queue + QUEUE_ENTRIES);
+    constexpr unsigned long long NOTHING = ~0ull;
+    if (HAS_TRI) found[lane] = NOTHING;
     // The bounds assume a unit direction; the as-written fuzzy metal leaves it unnormalised.
     const bool cull = (P.flags & 1u) == 0u;
     constexpr uint32_t NONE = 0xffffffffu;
@@ -559,35 +574,93 @@ void trace_kernel(const TraceParams P,
                 take_if_closer(best, __float_as_uint(t) - Window<SEM>::tmin, __float_as_uint(cub[4u * i + 3u].x));
             }
         }
-        // Triangles: walk the four-level bounding-sphere tree with the whole wave; a
-        // subtree is entered when the ray of any live lane can touch its sphere.
-        for (uint32_t i3 = 0; i3 < L.node_n[3]; ++i3) {
-            if (STATS) ++n_node;
-            if (cull && !__any(bound_hit<SEM>(node3[i3], o, d, best.key))) continue;
-            const uint32_t e2 = min(TREE_FAN * i3 + TREE_FAN, L.node_n[2]);
-            for (uint32_t i2 = TREE_FAN * i3; i2 < e2; ++i2) {
+        // Triangles: walk the four-level bounding-sphere tree with the whole wave; a subtree is entered when the
+        // ray of any live lane can touch its sphere.  At a leaf only the lanes whose rays touch it have any business
+        // with its triangles — typically a few of the 64, since bounce rays share little — so they do not test
+        // them on the spot (which would occupy the whole wave four times per leaf) but queue (lane, leaf).  Whenever
+        // the queue holds a pass worth of pairs, the wave tests them side by side: four lanes per pair, one per
+        // triangle, each fetching the ray of the pair's lane across the wave.  A crossing goes to the slot of the
+        // ray's lane by an atomic minimum on (key, id) — the same order-independent minimum as everywhere else —
+        // and every lane folds its slot into its closest hit when the walk is over.
+        if (HAS_TRI) {
+            const unsigned long long live = __ballot(1);
+            const uint32_t n_live = (uint32_t)__popcll(live);
+            const uint32_t lane_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
+            const bool spread = n_live >= 16u;                    // fewer live lanes: test at the leaf, as a wave
+            const uint32_t per_pass = n_live >> 2;                // pairs one pass takes
+            uint32_t q_head = 0u, q_len = 0u;                     // wave-uniform
+            auto pass = [&](uint32_t count) {
+                const uint32_t e = lane_rank >> 2, k = lane_rank & 3u;
+                const bool work = e < count;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t ent = work ? queue[(q_head + e) & (QUEUE_ENTRIES - 1u)] : (lane << 24);
+                const uint32_t src = ent >> 24, leaf = ent & 0xffffffu;
+                // the pair's ray: a read across the wave needs its source lane enabled, so every lane takes part
+                const int from = (int)(src << 2);
+                const V3 ro = v3(__uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(o.x))),
+                                 __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(o.y))),
+                                 __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(o.z))));
+                const V3 rd = v3(__uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(d.x))),
+                                 __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(d.y))),
+                                 __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(d.z))));
+                if (work) {
+                    const float4* const t4 = tri + 4u * (TREE_LEAF * leaf + k);
+                    const float4 w0 = t4[0], w1 = t4[1], w2 = t4[2], w3 = t4[3];
+                    uint32_t ckey, cid;
+                    const bool inside = triangle_candidate<SEM>(w0, w1, w2, w3, n_shapes, ro, rd, ckey, cid);
+                    if (inside && ckey < Window<SEM>::far - Window<SEM>::tmin)
+                        atomicMin(&found[src], ((unsigned long long)ckey << 32) | cid);
+                    if (STATS) ++n_tri;
+                }
+            };
+            for (uint32_t i3 = 0; i3 < L.node_n[3]; ++i3) {
                 if (STATS) ++n_node;
-                if (cull && !__any(bound_hit<SEM>(node2[i2], o, d, best.key))) continue;
-                const uint32_t e1 = min(TREE_FAN * i2 + TREE_FAN, L.node_n[1]);
-                for (uint32_t i1 = TREE_FAN * i2; i1 < e1; ++i1) {
+                if (cull && !__any(bound_hit<SEM>(node3[i3], o, d, best.key))) continue;
+                const uint32_t e2 = min(TREE_FAN * i3 + TREE_FAN, L.node_n[2]);
+                for (uint32_t i2 = TREE_FAN * i3; i2 < e2; ++i2) {
                     if (STATS) ++n_node;
-                    if (cull && !__any(bound_hit<SEM>(node1[i1], o, d, best.key))) continue;
-                    const uint32_t e0 = min(TREE_FAN * i1 + TREE_FAN, L.node_n[0]);
-                    for (uint32_t i0 = TREE_FAN * i1; i0 < e0; ++i0) {
+                    if (cull && !__any(bound_hit<SEM>(node2[i2], o, d, best.key))) continue;
+                    const uint32_t e1 = min(TREE_FAN * i2 + TREE_FAN, L.node_n[1]);
+                    for (uint32_t i1 = TREE_FAN * i2; i1 < e1; ++i1) {
                         if (STATS) ++n_node;
-                        if (cull && !__any(bound_hit<SEM>(node0[i0], o, d, best.key))) continue;
+                        if (cull && !__any(bound_hit<SEM>(node1[i1], o, d, best.key))) continue;
+                        const uint32_t e0 = min(TREE_FAN * i1 + TREE_FAN, L.node_n[0]);
+                        for (uint32_t i0 = TREE_FAN * i1; i0 < e0; ++i0) {
+                            if (STATS) ++n_node;
+                            const bool touch = !cull || bound_hit<SEM>(node0[i0], o, d, best.key);
+                            const unsigned long long touching = __ballot(touch);
+                            if (touching == 0ull) continue;
+                            if (spread) {
+                                const uint32_t at = q_head + q_len +
+                                    __builtin_amdgcn_mbcnt_hi((uint32_t)(touching >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching, 0u));
+                                if (touch) queue[at & (QUEUE_ENTRIES - 1u)] = (lane << 24) | i0;
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                                q_len += (uint32_t)__popcll(touching);
+                                while (q_len >= per_pass) { pass(per_pass); q_head += per_pass; q_len -= per_pass; }
+                                continue;
+                            }
 #pragma unroll
-                        for (uint32_t k = 0; k < TREE_LEAF; ++k) {
-                            const uint32_t ti = TREE_LEAF * i0 + k;
-                            float4 w0 = tri[4u * ti], w1 = tri[4u * ti + 1u], w2 = tri[4u * ti + 2u], w3 = tri[4u * ti + 3u];
-                            // Only xyz of two of the words is used, which would let the compiler
-                            // fetch 12 bytes each — and a 12-byte LDS read costs twice the LDS
-                            // cycles of a 16-byte one.
-                            if (!TRI_GLOBAL) asm volatile("" : "+v"(w2.w), "+v"(w3.w));
-                            test_triangle<SEM>(w0, w1, w2, w3, n_shapes, o, d, best);
+                            for (uint32_t k = 0; k < TREE_LEAF; ++k) {
+                                const uint32_t ti = TREE_LEAF * i0 + k;
+                                float4 w0 = tri[4u * ti], w1 = tri[4u * ti + 1u], w2 = tri[4u * ti + 2u], w3 = tri[4u * ti + 3u];
+                                // Only xyz of two of the words is used, which would let the compiler
+                                // fetch 12 bytes each — and a 12-byte LDS read costs twice the LDS
+                                // cycles of a 16-byte one.
+                                if (!TRI_GLOBAL) asm volatile("" : "+v"(w2.w), "+v"(w3.w));
+                                test_triangle<SEM>(w0, w1, w2, w3, n_shapes, o, d, best);
+                            }
+                            if (STATS) n_tri += TREE_LEAF;
                         }
-                        if (STATS) n_tri += TREE_LEAF;
                     }
+                }
+            }
+            if (spread) {
+                while (q_len != 0u) { const uint32_t c = min(q_len, per_pass); pass(c); q_head += c; q_len -= c; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const unsigned long long f = found[lane];
+                if (f != NOTHING) {
+                    take_if_closer(best, (uint32_t)(f >> 32), (uint32_t)f);
+                    found[lane] = NOTHING;
                 }
             }
         }
@@ -967,12 +1040,15 @@ hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams
 {
     const dim3 grid(n_workgroups * (4u / P.group_waves));
     const float4* b = static_cast<const float4*>(blob);
-    const size_t lds_bytes = (size_t)P.scene.lds_words * 16u;
-    const int geo = ((P.scene.n_tris != 0 && !P.scene.tri_in_lds) ? 1 : 0) | (((sem == 0 && P.scene.n_cube != 0) || P.scene.has_glass || P.scene.tcol_off != 0) ? 2 : 0) | (P.rng_mode ? 4 : 0);
+    const int tri_mode = P.scene.n_tris == 0 ? 0 : (P.scene.tri_in_lds ? 1 : 2);
+    const size_t lds_bytes = ((size_t)P.scene.lds_words + (tri_mode ? LDS_WAVE_WORDS_PER_GROUP : 0u)) * 16u;
+    const int geo = tri_mode | (((sem == 0 && P.scene.n_cube != 0) || P.scene.has_glass || P.scene.tcol_off != 0) ? 4 : 0) | (P.rng_mode ? 8 : 0);
 #define RT_CASE(S, G, M) if (sem == S && geo == G && mode == M) return launch_one<S, G, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm, tile_order, tile_cost)
 #define RT_CASES(S, G) RT_CASE(S, G, 0); RT_CASE(S, G, 1); RT_CASE(S, G, 2)
-    RT_CASES(0, 0); RT_CASES(0, 1); RT_CASES(0, 2); RT_CASES(0, 3); RT_CASES(0, 4); RT_CASES(0, 5); RT_CASES(0, 6); RT_CASES(0, 7);
-    RT_CASES(1, 0); RT_CASES(1, 1); RT_CASES(1, 2); RT_CASES(1, 3); RT_CASES(1, 4); RT_CASES(1, 5); RT_CASES(1, 6); RT_CASES(1, 7);
+#define RT_GEOS(S) RT_CASES(S, 0); RT_CASES(S, 1); RT_CASES(S, 2); RT_CASES(S, 4); RT_CASES(S, 5); RT_CASES(S, 6); \
+                   RT_CASES(S, 8); RT_CASES(S, 9); RT_CASES(S, 10); RT_CASES(S, 12); RT_CASES(S, 13); RT_CASES(S, 14)
+    RT_GEOS(0); RT_GEOS(1);
+#undef RT_GEOS
 #undef RT_CASES
 #undef RT_CASE
     return hipErrorInvalidValue;
