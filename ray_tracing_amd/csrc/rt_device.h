@@ -86,9 +86,12 @@ constexpr int BLOCK = 256;
 constexpr uint32_t LDS_FULL_OCCUPANCY_BYTES = 20u * 1024u;
 constexpr uint32_t LDS_MAX_BYTES = 64u * 1024u;
 // With triangles in the scene every wave of a workgroup owns, behind the staged scene, a queue of (lane, leaf)
-// pairs (QUEUE_ENTRIES x 4 bytes) and one 8-byte slot per lane for the closest triangle found.
-constexpr uint32_t QUEUE_ENTRIES = 128u;
-constexpr uint32_t WAVE_LDS_WORDS = (QUEUE_ENTRIES * 4u + 64u * 8u) / 16u;
+// pairs (QUEUE_ENTRIES x 4 bytes), one 8-byte slot per lane for the closest triangle found, and a queue of
+// (lane, level-1 node) pairs (NODE_QUEUE_ENTRIES x 4 bytes).  A node is queued only while fewer than SPREAD_BELOW
+// lanes touch it (more: the wave tests the node's leaves itself), and a queue is emptied whenever it holds a
+// full pass (at most 8 and 16 pairs), which bounds what they must hold.
+constexpr uint32_t QUEUE_ENTRIES = 128u, NODE_QUEUE_ENTRIES = 32u, SPREAD_BELOW = 24u;
+constexpr uint32_t WAVE_LDS_WORDS = (QUEUE_ENTRIES * 4u + 64u * 8u + NODE_QUEUE_ENTRIES * 4u) / 16u;
 constexpr uint32_t LDS_WAVE_WORDS_PER_GROUP = (BLOCK / 64) * WAVE_LDS_WORDS;
 
 }  // namespace rtd

@@ -534,6 +534,7 @@ void trace_kernel(const TraceParams P,
     // one slot per lane for the closest triangle those tests found.
     uint32_t* const queue = reinterpret_cast<uint32_t*>(lds + L.lds_words + (tid >> 6) * WAVE_LDS_WORDS);
     unsigned long long* const found = reinterpret_cast<unsigned long long*>(queue + QUEUE_ENTRIES);
+    uint32_t* const node_queue = queue + QUEUE_ENTRIES + 128u;              // (lane, level-1 node) pairs, NODE_QUEUE_ENTRIES
     constexpr unsigned long long NOTHING = ~0ull;
     if (HAS_TRI) found[lane] = NOTHING;
     // The bounds assume a unit direction; the as-written fuzzy metal leaves it unnormalised.
@@ -613,6 +614,39 @@ void trace_kernel(const TraceParams P,
                     if (STATS) ++n_tri;
                 }
             };
+            // Pairs (lane, leaf) go to the triangle queue; full passes are run at once.
+            auto push_leaves = [&](bool touch, uint32_t src, uint32_t leaf) {
+                const unsigned long long touching = __ballot(touch);
+                const uint32_t at = q_head + q_len +
+                    __builtin_amdgcn_mbcnt_hi((uint32_t)(touching >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching, 0u));
+                if (touch) queue[at & (QUEUE_ENTRIES - 1u)] = (src << 24) | leaf;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                q_len += (uint32_t)__popcll(touching);
+                while (q_len >= per_pass) { pass(per_pass); q_head += per_pass; q_len -= per_pass; }
+            };
+            // The same one level up: eight lanes per queued (lane, level-1 node) pair, one per leaf of the node,
+            // test the leaf's bound against the pair's ray.
+            const uint32_t node_pass = n_live >> 3;               // pairs one pass takes
+            uint32_t nq_head = 0u, nq_len = 0u;
+            auto bound_pass = [&](uint32_t count) {
+                const uint32_t e = lane_rank >> 3, c = lane_rank & 7u;
+                const bool work = e < count;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t ent = work ? node_queue[(nq_head + e) & (NODE_QUEUE_ENTRIES - 1u)] : (lane << 24);
+                const uint32_t src = ent >> 24, i0 = TREE_FAN * (ent & 0xffffffu) + c;
+                const int from = (int)(src << 2);
+                const V3 ro = v3(__uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(o.x))),
+                                 __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(o.y))),
+                                 __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(o.z))));
+                const V3 rd = v3(__uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(d.x))),
+                                 __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(d.y))),
+                                 __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(d.z))));
+                const uint32_t rkey = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)best.key);
+                const bool valid = work && i0 < L.node_n[0];
+                const bool touch = valid && bound_hit<SEM>(node0[valid ? i0 : 0u], ro, rd, rkey);
+                if (STATS && valid) ++n_node;
+                push_leaves(touch, src, i0);
+            };
             for (uint32_t i3 = 0; i3 < L.node_n[3]; ++i3) {
                 if (STATS) ++n_node;
                 if (cull && !__any(bound_hit<SEM>(node3[i3], o, d, best.key))) continue;
@@ -623,22 +657,28 @@ void trace_kernel(const TraceParams P,
                     const uint32_t e1 = min(TREE_FAN * i2 + TREE_FAN, L.node_n[1]);
                     for (uint32_t i1 = TREE_FAN * i2; i1 < e1; ++i1) {
                         if (STATS) ++n_node;
-                        if (cull && !__any(bound_hit<SEM>(node1[i1], o, d, best.key))) continue;
+                        const bool touch1 = !cull || bound_hit<SEM>(node1[i1], o, d, best.key);
+                        const unsigned long long touching1 = __ballot(touch1);
+                        if (touching1 == 0ull) continue;
+                        const uint32_t n_touching1 = (uint32_t)__popcll(touching1);
+                        if (spread && n_touching1 < SPREAD_BELOW) {
+                            // Few lanes are interested in this node: rather than have the whole wave test each of
+                            // its leaves' bounds, queue (lane, node); a pass tests eight leaves' bounds per pair.
+                            const uint32_t at = nq_head + nq_len +
+                                __builtin_amdgcn_mbcnt_hi((uint32_t)(touching1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching1, 0u));
+                            if (touch1) node_queue[at & (NODE_QUEUE_ENTRIES - 1u)] = (lane << 24) | i1;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            nq_len += n_touching1;
+                            while (nq_len >= node_pass) { bound_pass(node_pass); nq_head += node_pass; nq_len -= node_pass; }
+                            continue;
+                        }
                         const uint32_t e0 = min(TREE_FAN * i1 + TREE_FAN, L.node_n[0]);
                         for (uint32_t i0 = TREE_FAN * i1; i0 < e0; ++i0) {
                             if (STATS) ++n_node;
                             const bool touch = !cull || bound_hit<SEM>(node0[i0], o, d, best.key);
                             const unsigned long long touching = __ballot(touch);
                             if (touching == 0ull) continue;
-                            if (spread) {
-                                const uint32_t at = q_head + q_len +
-                                    __builtin_amdgcn_mbcnt_hi((uint32_t)(touching >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching, 0u));
-                                if (touch) queue[at & (QUEUE_ENTRIES - 1u)] = (lane << 24) | i0;
-                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                                q_len += (uint32_t)__popcll(touching);
-                                while (q_len >= per_pass) { pass(per_pass); q_head += per_pass; q_len -= per_pass; }
-                                continue;
-                            }
+                            if (spread) { push_leaves(touch, lane, i0); continue; }
 #pragma unroll
                             for (uint32_t k = 0; k < TREE_LEAF; ++k) {
                                 const uint32_t ti = TREE_LEAF * i0 + k;
@@ -655,6 +695,7 @@ void trace_kernel(const TraceParams P,
                 }
             }
             if (spread) {
+                while (nq_len != 0u) { const uint32_t c = min(nq_len, node_pass); bound_pass(c); nq_head += c; nq_len -= c; }
                 while (q_len != 0u) { const uint32_t c = min(q_len, per_pass); pass(c); q_head += c; q_len -= c; }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const unsigned long long f = found[lane];
