@@ -272,17 +272,19 @@ static int build_blob(rt_ctx* ctx)
         }
         // The top level is scanned linearly, so it is not grouped any further.
     }
-    L.cub_off = L.box_off + 2u * n_box;
+    L.cub_off = L.box_off + 3u * n_box;
     uint32_t off = L.cub_off + 4u * n_cube;
     for (int l = (int)rtd::TREE_LEVELS - 1; l >= 0; --l) { L.node_off[l] = off; off += node_pad[l]; }
-    L.inv_off = off;
-    L.tri_off = L.inv_off + (n_tris + 3u) / 4u;
-    L.total_words = L.tri_off + 4u * n_tri_pad;
+    L.tri_off = off;
+    const uint32_t staged_words = L.tri_off + 4u * n_tri_pad;        // what a workgroup stages when the mesh fits
+    // The place of each uploaded triangle in the sorted list is looked up once per hit: it stays in global memory.
+    L.inv_off = staged_words;
+    L.total_words = L.inv_off + (n_tris + 3u) / 4u;
     const bool colors = !ctx->tri_colors.empty() && ctx->tri_colors.size() == 3u * (size_t)n_tris;
-    const uint32_t wave_words = n_tris ? rtd::LDS_WAVE_WORDS_PER_GROUP : 0u;       // queues and slots of the triangle tests
+    const uint32_t wave_words = (n_tris || n_box) ? rtd::LDS_WAVE_WORDS_PER_GROUP : 0u;     // queues and slots of the spread tests
     if ((size_t)(L.node_off[rtd::TREE_LEVELS - 1u] + wave_words) * 16u > rtd::LDS_MAX_BYTES)
         return fail(ctx, RT_ERR_INVALID_ARG, "scene: %u shapes need more than the %u-byte LDS stage", n_shapes, rtd::LDS_MAX_BYTES);
-    if ((size_t)(L.total_words + wave_words) * 16u <= rtd::LDS_MAX_BYTES) { L.lds_words = L.total_words; L.tri_in_lds = 1; }
+    if ((size_t)(staged_words + wave_words) * 16u <= rtd::LDS_MAX_BYTES) { L.lds_words = staged_words; L.tri_in_lds = 1; }
     else { L.lds_words = L.node_off[rtd::TREE_LEVELS - 1u]; L.tri_in_lds = 0; }     // the mesh and its tree stay in global memory
     // Per-triangle albedo: read only at a hit, so it stays in global memory behind everything else.
     if (colors) { L.tcol_off = L.total_words; L.total_words += n_tris; }
@@ -326,10 +328,15 @@ static int build_blob(rt_ctx* ctx)
             as_u32(blob[L.sid_off + is / 4u].f[is % 4u]) = i;
             ++is;
         } else if (s.type == RT_SHAPE_BOX) {
-            Word& w = blob[L.box_off + 2u * ib]; Word& w1 = blob[L.box_off + 2u * ib + 1u];
+            Word& w = blob[L.box_off + 3u * ib]; Word& w1 = blob[L.box_off + 3u * ib + 1u]; Word& w2 = blob[L.box_off + 3u * ib + 2u];
             w.f[0] = cx; w.f[1] = cy; w.f[2] = cz; w.f[3] = 1.0f / scale;
             as_u32(w1.f[0]) = i;
             w1.f[1] = 1.0f / side_y; w1.f[2] = 1.0f / side_z;
+            // Half extents of a box around everything the test can accept (points up to 0.5001 of a side from the
+            // centre along every axis, RayTracing.glsl:151), with slack for the rounding of the kernels' slab test.
+            const float sides[3] = { scale, side_y, side_z };
+            for (int k = 0; k < 3; ++k)
+                w2.f[k] = std::nextafter((float)(0.5001 * 1.0001 * std::fabs((double)sides[k]) + 1e-4), std::numeric_limits<float>::infinity());
             ++ib;
         } else if (s.type == RT_SHAPE_CUBE && ctx->cfg.semantics == RT_SEM_CPU) {
             Word* w = &blob[L.cub_off + 4u * ic];

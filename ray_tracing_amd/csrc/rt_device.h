@@ -22,15 +22,16 @@ namespace rtd {
 //   sph  [n_sph_pad]      spheres in upload order: centre.xyz, radius^2; padded to a
 //                         multiple of 4 with NaN centres (never hit)
 //   sid  [n_sph_pad / 4]  the spheres' shape indices, four per word
-//   box  [2 * n_box]      boxes in upload order: {centre.xyz, 1/side x}, {shape index, 1/side y, 1/side z, 0}
+//   box  [3 * n_box]      boxes in upload order: {centre.xyz, 1/side x}, {shape index, 1/side y, 1/side z, 0},
+//                         {half extents of the bounding box that holds everything the test accepts, 0}
 //                         (the three sides are equal unless the context asks for a Box's own sides)
 //   cub  [4 * n_cube]     the CPU tracer's cubes in upload order: rows of the rotation with the
 //                         centre, {R(i,0), R(i,1), R(i,2), c_i} for i = 0..2, then {shape index, 0, 0, 0}
 //   node [n3p+n2p+n1p+n0p] bounding spheres over the triangles, four levels (below)
-//   inv  [n_tris / 4]     for each uploaded triangle, its place in the sorted list (uint32)
 //   tri  [4 * n_tri_pad]  SimpleTriangles ordered by recursive median splits and padded to a
 //                         multiple of TREE_LEAF with never-hit ones: {position.xyz, index in
 //                         the uploaded array}, {a.xyz, beta}, {m1}, {m2}
+//   inv  [n_tris / 4]     never staged in LDS: for each uploaded triangle, its place in the sorted list (uint32)
 //   tcol [n_tris]         optional, never staged in LDS: albedo.rgb of each uploaded triangle (x 0.6 under CPU rules)
 //
 // Bounding-sphere tree: level 0 node i bounds the sorted triangles [TREE_LEAF*i,
@@ -47,7 +48,7 @@ struct SceneLayout {
     uint32_t node_n[TREE_LEVELS];                           // real (unpadded) node counts
     uint32_t total_words;                                   // whole blob
     uint32_t lds_words;                                     // prefix staged in LDS
-    uint32_t tri_in_lds;                                    // 1 if inv and tri are part of that prefix
+    uint32_t tri_in_lds;                                    // 1 if the tree and tri are part of that prefix
     uint32_t has_glass;                                     // 1 if any shape has the dielectric material
     uint32_t tcol_off;                                      // 0: all triangles share TraceParams::tri_albedo
 };

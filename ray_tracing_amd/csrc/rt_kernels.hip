@@ -366,6 +366,23 @@ RT_DEV bool bound_hit(float4 nb, V3 o, V3 d, uint32_t best_key)
     return fma_(b, b, rhs) >= oc2 && (b < 0.0f || oc2 <= rhs) && (b + nb.w) >= lim;
 }
 
+// Can the ray touch the axis-aligned box {centre c, half extents h}?  Slab test with the reciprocal direction: along
+// each axis the ray is inside the slab for t in [tc - hw, tc + hw], tc = (c - o) / d, hw = h / |d|; it touches the box
+// when the latest entry is not after the earliest exit (a relative 1e-5 and an absolute 1e-6 cover the rounding of both,
+// on top of the slack in h), the exit is not behind the origin and the entry not beyond the closest hit so far.  Written
+// with negated comparisons: a NaN (0 * infinity: origin on a slab's plane and no movement along that axis) lets the ray
+// through.
+template <int SEM>
+RT_DEV bool box_bound_hit(float4 c, float4 h, V3 o, V3 inv_d, uint32_t best_key)
+{
+    const float tcx = (c.x - o.x) * inv_d.x, tcy = (c.y - o.y) * inv_d.y, tcz = (c.z - o.z) * inv_d.z;
+    const float hwx = h.x * __builtin_fabsf(inv_d.x), hwy = h.y * __builtin_fabsf(inv_d.y), hwz = h.z * __builtin_fabsf(inv_d.z);
+    const float t_in = __builtin_fmaxf(__builtin_fmaxf(tcx - hwx, tcy - hwy), tcz - hwz);
+    const float t_out = __builtin_fminf(__builtin_fminf(tcx + hwx, tcy + hwy), tcz + hwz);
+    const float lim = __uint_as_float(best_key + Window<SEM>::tmin) * 1.00001f;
+    return !(t_in > fma_(__builtin_fabsf(t_out), 1e-5f, t_out + 1e-6f)) && !(t_out < 0.0f) && !(t_in > lim);
+}
+
 // uvec4(255 * color), RayTracing.glsl:301; negative and NaN give 0, large
 // values saturate (v_cvt_u32_f32 does exactly that).
 RT_DEV uint32_t quantise(float c)
@@ -377,8 +394,8 @@ RT_DEV uint32_t quantise(float c)
 // -------------------------------------------------------------- the tracer
 // SEM 0: rules of src/cpu_version (rayTracer.h:110-132, scene.h:39-109).
 // SEM 1: rules of RayTracing.glsl:233-288.
-// GEO bits 0-1: 0 no triangles (the instance has no traversal code), 1 triangles staged in LDS, 2 triangles
-// and their tree read from the blob in global memory; bit 2: the scene holds cubes of the CPU tracer, dielectric
+// GEO bits 0-1: 0 spheres and cubes only (the instance has no traversal and no queue code), 1 boxes and / or
+// triangles staged in LDS, 2 triangles and their tree read from the blob in global memory; bit 2: the scene holds cubes of the CPU tracer, dielectric
 // materials or a colour per triangle (kept out of the other instances, whose registers and issue slots they
 // would cost: 12 % on the four-sphere scene); bit 3: draws come from the
 // shader's own random() instead of the counter hash.  MODE 0: render.  MODE 1: render and count work.  MODE 2:
@@ -390,7 +407,10 @@ RT_DEV uint32_t quantise(float c)
 // two random draws and the normalisation of the new direction — are issued
 // once for the whole wave, whether a lane is bouncing or starting a sample.
 template <int SEM, int GEO, int MODE>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ __launch_bounds__(BLOCK)
+// Spheres only: 64 registers, eight waves per SIMD.  With boxes or a mesh the staged scene and the wave's queues
+// leave room for six workgroups per CU at most, so those instances may use the registers of six waves per SIMD.
+__attribute__((amdgpu_waves_per_eu((GEO & 3) != 0 ? 6 : 8, 8)))
 void trace_kernel(const TraceParams P,
                   const float4* __restrict__ blob,
                   uint32_t* __restrict__ accum,
@@ -402,7 +422,7 @@ void trace_kernel(const TraceParams P,
 {
     constexpr bool STATS = MODE == 1, TRACE = MODE == 2;
     constexpr bool COST_CLOCK = RT_COST_CLOCK != 0;        // a tile's cost: shader clocks of its slowest wave, not loop iterations
-    constexpr bool HAS_TRI = (GEO & 3) != 0, TRI_GLOBAL = (GEO & 3) == 2, HAS_CUBE = SEM == 0 && (GEO & 4) != 0, HAS_GLASS = (GEO & 4) != 0, HAS_TCOL = (GEO & 4) != 0, RNG_GLSL = (GEO & 8) != 0;
+    constexpr bool HAS_TRI = (GEO & 3) != 0, TRI_GLOBAL = (GEO & 3) == 2, SPREAD_BOXES = HAS_TRI, HAS_CUBE = SEM == 0 && (GEO & 4) != 0, HAS_GLASS = (GEO & 4) != 0, HAS_TCOL = (GEO & 4) != 0, RNG_GLSL = (GEO & 8) != 0;
     extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -521,7 +541,7 @@ void trace_kernel(const TraceParams P,
     const float4* const rec = lds + L.rec_off;
     const float4* const cub = lds + L.cub_off;
     const float4* const tri = TRI_GLOBAL ? blob + L.tri_off : lds + L.tri_off;
-    const uint32_t* const slot_of = reinterpret_cast<const uint32_t*>(TRI_GLOBAL ? blob + L.inv_off : lds + L.inv_off);
+    const uint32_t* const slot_of = reinterpret_cast<const uint32_t*>(blob + L.inv_off);        // read once per triangle hit: global memory
     // The tree over a staged mesh is staged with it; that of a mesh in global memory is read from there too
     // (measured on the 4 968-triangle mesh: where its tree lives makes no difference, 120-123 ms either way).
     const float4* const nodes = TRI_GLOBAL ? blob : lds;
@@ -563,10 +583,65 @@ void trace_kernel(const TraceParams P,
             test_sphere<SEM>(s2, __float_as_uint(ids.z), o, d, best);
             test_sphere<SEM>(s3, __float_as_uint(ids.w), o, d, best);
         }
-        for (uint32_t i = 0; i < n_box; ++i) {
-            const float4 bx = box[2u * i];
-            const float4 bx1 = box[2u * i + 1u];
-            take_if_closer(best, __float_as_uint(hit_box(bx, bx1.y, bx1.z, o, d)) - Window<SEM>::tmin, __float_as_uint(bx1.x));
+        // The lanes still tracing, and this lane's place among them: they share the queued tests.
+        uint32_t n_live = 64u, lane_rank = lane;
+        if (HAS_TRI) {
+            const unsigned long long live = __ballot(1);
+            n_live = (uint32_t)__popcll(live);
+            lane_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
+        }
+        const bool spread = HAS_TRI && n_live >= 16u;             // fewer live lanes: every test as a wave
+        // Boxes.  The full test is long (three reciprocals, three candidate points); a lane needs it only for a box
+        // whose bounding sphere its ray touches.  Those (lane, box) pairs are queued and tested one lane per pair.
+        if (SPREAD_BOXES && spread && cull) {
+            uint32_t bq_len = 0u;                                 // wave-uniform
+            // 1 / d for the slab test of the bounds: hardware reciprocals (within an ulp; a zero component gives an
+            // infinity) — the bounds carry the slack for that, and decide nothing but who runs the exact test.
+            const V3 inv_d = v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+            auto box_pass = [&](uint32_t count) {
+                const bool work = lane_rank < count;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t ent = work ? queue[lane_rank] : (lane << 24);
+                const uint32_t src = ent >> 24, i = ent & 0xffffffu;
+                const int from = (int)(src << 2);
+                const V3 ro = v3(__uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(o.x))),
+                                 __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(o.y))),
+                                 __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(o.z))));
+                const V3 rd = v3(__uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(d.x))),
+                                 __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(d.y))),
+                                 __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(d.z))));
+                if (work) {
+                    const float4 bx = box[3u * i], bx1 = box[3u * i + 1u];
+                    const uint32_t ckey = __float_as_uint(hit_box(bx, bx1.y, bx1.z, ro, rd)) - Window<SEM>::tmin;
+                    if (ckey < Window<SEM>::far - Window<SEM>::tmin)
+                        atomicMin(&found[src], ((unsigned long long)ckey << 32) | __float_as_uint(bx1.x));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            };
+            for (uint32_t i = 0; i < n_box; ++i) {
+                const bool touch = box_bound_hit<SEM>(box[3u * i], box[3u * i + 2u], o, inv_d, best.key);
+                const unsigned long long touching = __ballot(touch);
+                if (touching == 0ull) continue;
+                const uint32_t n_touching = (uint32_t)__popcll(touching);
+                if (bq_len + n_touching > n_live) { box_pass(bq_len); bq_len = 0u; }      // a pass takes one pair per live lane
+                const uint32_t at = bq_len + __builtin_amdgcn_mbcnt_hi((uint32_t)(touching >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching, 0u));
+                if (touch) queue[at] = (lane << 24) | i;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                bq_len += n_touching;
+            }
+            if (bq_len != 0u) box_pass(bq_len);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const unsigned long long f = found[lane];
+            if (f != NOTHING) {
+                take_if_closer(best, (uint32_t)(f >> 32), (uint32_t)f);
+                found[lane] = NOTHING;
+            }
+        } else {
+            for (uint32_t i = 0; i < n_box; ++i) {
+                const float4 bx = box[3u * i];
+                const float4 bx1 = box[3u * i + 1u];
+                take_if_closer(best, __float_as_uint(hit_box(bx, bx1.y, bx1.z, o, d)) - Window<SEM>::tmin, __float_as_uint(bx1.x));
+            }
         }
         if (HAS_CUBE) {
             for (uint32_t i = 0; i < L.n_cube; ++i) {
@@ -584,10 +659,6 @@ void trace_kernel(const TraceParams P,
         // ray's lane by an atomic minimum on (key, id) — the same order-independent minimum as everywhere else —
         // and every lane folds its slot into its closest hit when the walk is over.
         if (HAS_TRI) {
-            const unsigned long long live = __ballot(1);
-            const uint32_t n_live = (uint32_t)__popcll(live);
-            const uint32_t lane_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
-            const bool spread = n_live >= 16u;                    // fewer live lanes: test at the leaf, as a wave
             const uint32_t per_pass = n_live >> 2;                // pairs one pass takes
             uint32_t q_head = 0u, q_len = 0u;                     // wave-uniform
             auto pass = [&](uint32_t count) {
@@ -1081,7 +1152,7 @@ hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams
 {
     const dim3 grid(n_workgroups * (4u / P.group_waves));
     const float4* b = static_cast<const float4*>(blob);
-    const int tri_mode = P.scene.n_tris == 0 ? 0 : (P.scene.tri_in_lds ? 1 : 2);
+    const int tri_mode = P.scene.n_tris == 0 ? (P.scene.n_box != 0 ? 1 : 0) : (P.scene.tri_in_lds ? 1 : 2);
     const size_t lds_bytes = ((size_t)P.scene.lds_words + (tri_mode ? LDS_WAVE_WORDS_PER_GROUP : 0u)) * 16u;
     const int geo = tri_mode | (((sem == 0 && P.scene.n_cube != 0) || P.scene.has_glass || P.scene.tcol_off != 0) ? 4 : 0) | (P.rng_mode ? 8 : 0);
 #define RT_CASE(S, G, M) if (sem == S && geo == G && mode == M) return launch_one<S, G, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm, tile_order, tile_cost)
