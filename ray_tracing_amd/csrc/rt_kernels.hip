@@ -659,10 +659,10 @@ void trace_kernel(const TraceParams P,
         // ray's lane by an atomic minimum on (key, id) — the same order-independent minimum as everywhere else —
         // and every lane folds its slot into its closest hit when the walk is over.
         if (HAS_TRI) {
-            const uint32_t per_pass = n_live >> 2;                // pairs one pass takes
+            const uint32_t per_pass = n_live / TREE_LEAF;         // pairs one pass takes: TREE_LEAF lanes each
             uint32_t q_head = 0u, q_len = 0u;                     // wave-uniform
             auto pass = [&](uint32_t count) {
-                const uint32_t e = lane_rank >> 2, k = lane_rank & 3u;
+                const uint32_t e = lane_rank / TREE_LEAF, k = lane_rank % TREE_LEAF;
                 const bool work = e < count;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const uint32_t ent = work ? queue[(q_head + e) & (QUEUE_ENTRIES - 1u)] : (lane << 24);
