@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 # a terminal event (light / miss) ~3.
 F_SPHERE, F_BOX, F_TRI = 20, 58, 32
 F_BOUND = 20                          # one ray / bounding-sphere test of the triangle tree (3 sub, 2 dots, R*R, 2 fma, limit mul, add)
+F_BOX_BOUND = 21                      # one slab test of a box's bounds (3 sub, 6 mul, 6 add/sub, 2 max, 2 min, fma, add)
 F_CAMERA, F_DIFFUSE, F_SPECULAR, F_TERMINAL = 25 + 2 * 11, 90, 30, 3
 PEAK_FP32_VECTOR_TFLOPS = 157.3       # 256 CU x 4 SIMD x 64 flop/clk x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
@@ -35,10 +36,11 @@ PEAK_CLOCK_HZ, N_SIMD = 2.4e9, 1024
 
 
 def algorithmic_flops(st, executed=True):
-    """Flops of one launch.  executed=True prices the tests the kernel really ran (it culls triangles by
-    bounding spheres); executed=False prices the reference's exhaustive scan of every triangle."""
+    """Flops of one launch.  executed=True prices the tests the kernel really ran (it culls triangles and boxes by
+    their bounds); executed=False prices the reference's exhaustive scan of every triangle and box."""
     tri = st["triangle_tests_done"] * F_TRI + st["bound_tests_done"] * F_BOUND if executed else st["triangle_tests"] * F_TRI
-    return (st["samples"] * F_CAMERA + st["sphere_tests"] * F_SPHERE + st["box_tests"] * F_BOX + tri +
+    box = st["box_tests_done"] * F_BOX + st["box_bound_tests_done"] * F_BOX_BOUND if executed else st["box_tests"] * F_BOX
+    return (st["samples"] * F_CAMERA + st["sphere_tests"] * F_SPHERE + box + tri +
             st["diffuse"] * F_DIFFUSE + st["specular"] * F_SPECULAR + st["terminal"] * F_TERMINAL)
 
 

@@ -148,12 +148,14 @@ typedef struct rt_stats {
     uint64_t terminal;         /* paths ended by light, miss, absorb or depth    */
     uint64_t shape_tests;      /* ray-sphere + ray-box tests                     */
     uint64_t sphere_tests;
-    uint64_t box_tests;
+    uint64_t box_tests;        /* ... of these, ray-box: what the reference's scan does, segments x boxes */
     uint64_t triangle_tests;   /* what the reference's exhaustive scan does: segments x triangles */
     uint64_t triangle_tests_done;  /* ray-triangle tests this library executed (it culls by bounding spheres) */
     uint64_t bound_tests_done;     /* ray-bounding-sphere tests it executed to do so */
     uint64_t wave_iterations;      /* loop iterations summed over waves: segments / (64 * this) = lane use */
     uint64_t work_units;           /* workgroups that traced: the tiles, plus one per extra slice of a tile's sample range */
+    uint64_t box_tests_done;       /* ray-box tests this library executed (it culls by the boxes' bounds) */
+    uint64_t box_bound_tests_done; /* slab tests of those bounds it executed to do so */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

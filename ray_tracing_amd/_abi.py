@@ -40,7 +40,8 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "segments", "diffuse", "specular", "terminal",
                                           "shape_tests", "sphere_tests", "box_tests", "triangle_tests",
-                                          "triangle_tests_done", "bound_tests_done", "wave_iterations", "work_units")]
+                                          "triangle_tests_done", "bound_tests_done", "wave_iterations", "work_units",
+                                          "box_tests_done", "box_bound_tests_done")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -677,6 +677,8 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         stats->bound_tests_done = h[rtd::ST_NODE_TESTS];
         stats->wave_iterations = h[rtd::ST_WAVE_ITERS];
         stats->work_units = h[rtd::ST_UNITS];
+        stats->box_tests_done = h[rtd::ST_BOX_TESTS];
+        stats->box_bound_tests_done = h[rtd::ST_BOX_BOUNDS];
     }
     return RT_OK;
 }

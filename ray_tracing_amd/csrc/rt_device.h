@@ -74,7 +74,7 @@ struct TraceParams {
 };
 
 // Slots of the statistics block (uint64 each).
-enum { ST_SAMPLES = 0, ST_SEGMENTS, ST_DIFFUSE, ST_SPECULAR, ST_TERMINAL, ST_TRI_TESTS, ST_NODE_TESTS, ST_WAVE_ITERS, ST_UNITS, ST_COUNT };
+enum { ST_SAMPLES = 0, ST_SEGMENTS, ST_DIFFUSE, ST_SPECULAR, ST_TERMINAL, ST_TRI_TESTS, ST_NODE_TESTS, ST_WAVE_ITERS, ST_UNITS, ST_BOX_TESTS, ST_BOX_BOUNDS, ST_COUNT };
 
 constexpr int TILE_W = 16;     // pixels per workgroup in x (two 8-wide wave tiles)
 constexpr int TILE_H = 16;     // and in y

@@ -426,7 +426,7 @@ void trace_kernel(const TraceParams P,
     extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
-    uint32_t n_samples = 0, n_segments = 0, n_diffuse = 0, n_specular = 0, n_terminal = 0, n_tri = 0, n_node = 0, n_iterations = 0;
+    uint32_t n_samples = 0, n_segments = 0, n_diffuse = 0, n_specular = 0, n_terminal = 0, n_tri = 0, n_node = 0, n_iterations = 0, n_box_test = 0, n_box_bound = 0;
 
     // One 8x8-pixel tile per wave, four waves (a 16x16 tile) per workgroup; workgroups start in
     // blockIdx order.  `work` is the plan made from the previous frame of this view (tile_plan_kernel):
@@ -615,11 +615,13 @@ void trace_kernel(const TraceParams P,
                     const uint32_t ckey = __float_as_uint(hit_box(bx, bx1.y, bx1.z, ro, rd)) - Window<SEM>::tmin;
                     if (ckey < Window<SEM>::far - Window<SEM>::tmin)
                         atomicMin(&found[src], ((unsigned long long)ckey << 32) | __float_as_uint(bx1.x));
+                    if (STATS) ++n_box_test;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             };
             for (uint32_t i = 0; i < n_box; ++i) {
                 const bool touch = box_bound_hit<SEM>(box[3u * i], box[3u * i + 2u], o, inv_d, best.key);
+                if (STATS) ++n_box_bound;
                 const unsigned long long touching = __ballot(touch);
                 if (touching == 0ull) continue;
                 const uint32_t n_touching = (uint32_t)__popcll(touching);
@@ -642,6 +644,7 @@ void trace_kernel(const TraceParams P,
                 const float4 bx1 = box[3u * i + 1u];
                 take_if_closer(best, __float_as_uint(hit_box(bx, bx1.y, bx1.z, o, d)) - Window<SEM>::tmin, __float_as_uint(bx1.x));
             }
+            if (STATS) n_box_test += n_box;
         }
         if (HAS_CUBE) {
             for (uint32_t i = 0; i < L.n_cube; ++i) {
@@ -965,7 +968,7 @@ void trace_kernel(const TraceParams P,
     if (STATS) {
         // Sum over the wave with cross-lane shuffles, one atomic per wave and counter.
         uint32_t c[ST_COUNT] = { n_samples, n_segments, n_diffuse, n_specular, n_terminal, n_tri, n_node, (lane == 0u) ? n_iterations : 0u,
-                                 (tid == 0u && (q & 3u) == 0u) ? 1u : 0u };
+                                 (tid == 0u && (q & 3u) == 0u) ? 1u : 0u, n_box_test, n_box_bound };
 #pragma unroll
         for (int k = 0; k < ST_COUNT; ++k) {
             unsigned long long v = c[k];
