@@ -440,3 +440,28 @@ def test_mesh_larger_than_the_lds_stage(rta, orc):
     assert len(cfg.triangles) == 20000
     st = check_config(rta, orc, cfg)
     assert st["triangle_tests"] == st["segments"] * 20000
+
+
+def test_mesh_scene_without_culling(rta, orc):
+    """The as-written fuzzy metal leaves directions unnormalised (scene.h:78), which the bounds cannot assume: with
+    that flag every lane takes every leaf and every box, through the same queues."""
+    from ray_tracing_amd import host
+    cfg = rta.scenes.config3(width=64, height=36, spp=4, max_depth=6)
+    cfg.semantics = rta.SEM_CPU
+    cfg.flags = rta.FLAG_METAL_UNNORMALIZED
+    cfg.shapes = np.concatenate([cfg.shapes, host.pack([host.Circle((0.5, 0.6, -1.0), 0.4, host.Metal((0.9, 0.9, 0.9), fuzz=0.3))], cfg.shapes.dtype)])
+    check_config(rta, orc, cfg)
+
+
+def test_many_boxes_fill_more_than_one_pass(rta, orc):
+    """Forty boxes in view: the (lane, box) pairs of one ray segment exceed the 64 a pass takes."""
+    from ray_tracing_amd import host
+    rng = np.random.default_rng(5)
+    boxes = [host.Box((float(x), float(y), float(z)), (float(s), float(s), float(s)), host.Lambertian(tuple(rng.uniform(0.2, 1.0, 3))))
+             for x, y, z, s in zip(rng.uniform(-3, 5, 40), rng.uniform(0, 4, 40), rng.uniform(-8, -2, 40), rng.uniform(0.4, 1.6, 40))]
+    cfg = rta.scenes.config3(width=96, height=54, spp=4, max_depth=6)
+    cfg.shapes = np.concatenate([cfg.shapes, host.pack(boxes, cfg.shapes.dtype)])
+    cfg.triangles = cfg.triangles[:0]
+    st = check_config(rta, orc, cfg)
+    assert st["box_tests"] == st["segments"] * 44 and st["box_tests_done"] < st["box_tests"] // 2
+
