@@ -90,8 +90,16 @@ constexpr uint32_t LDS_MAX_BYTES = 64u * 1024u;
 // pairs (QUEUE_ENTRIES x 4 bytes), one 8-byte slot per lane for the closest triangle found, and a queue of
 // (lane, level-1 node) pairs (NODE_QUEUE_ENTRIES x 4 bytes).  A node is queued only while fewer than SPREAD_BELOW
 // lanes touch it (more: the wave tests the node's leaves itself), and a queue is emptied whenever it holds a
-// full pass (at most 8 and 16 pairs), which bounds what they must hold.
-constexpr uint32_t QUEUE_ENTRIES = 128u, NODE_QUEUE_ENTRIES = 32u, SPREAD_BELOW = 24u;
+// full pass (at most 8 and 16 pairs), which bounds what they must hold.  (Measured on the 292-triangle mesh scene:
+// thresholds of 16, 24 and 40 lanes give the same 20.0 ms, 57 gives 21.5, queueing always 23.3.)
+#ifndef RT_SPREAD_BELOW
+#define RT_SPREAD_BELOW 24
+#endif
+#ifndef RT_NODE_QUEUE_ENTRIES
+#define RT_NODE_QUEUE_ENTRIES 32
+#endif
+constexpr uint32_t QUEUE_ENTRIES = 128u, NODE_QUEUE_ENTRIES = RT_NODE_QUEUE_ENTRIES, SPREAD_BELOW = RT_SPREAD_BELOW;
+static_assert(SPREAD_BELOW - 1u + 7u < NODE_QUEUE_ENTRIES, "the node queue must hold a node's lanes on top of an unfinished pass");
 constexpr uint32_t WAVE_LDS_WORDS = (QUEUE_ENTRIES * 4u + 64u * 8u + NODE_QUEUE_ENTRIES * 4u) / 16u;
 constexpr uint32_t LDS_WAVE_WORDS_PER_GROUP = (BLOCK / 64) * WAVE_LDS_WORDS;
 
