@@ -86,21 +86,24 @@ constexpr int BLOCK = 256;
 // triangles and their tree stay in global memory.
 constexpr uint32_t LDS_FULL_OCCUPANCY_BYTES = 20u * 1024u;
 constexpr uint32_t LDS_MAX_BYTES = 64u * 1024u;
-// With triangles in the scene every wave of a workgroup owns, behind the staged scene, a queue of (lane, leaf)
-// pairs (QUEUE_ENTRIES x 4 bytes), one 8-byte slot per lane for the closest triangle found, and a queue of
-// (lane, level-1 node) pairs (NODE_QUEUE_ENTRIES x 4 bytes).  A node is queued only while fewer than SPREAD_BELOW
-// lanes touch it (more: the wave tests the node's leaves itself), and a queue is emptied whenever it holds a
-// full pass (at most 8 and 16 pairs), which bounds what they must hold.  (Measured on the 292-triangle mesh scene:
-// thresholds of 16, 24 and 40 lanes give the same 20.0 ms, 57 gives 21.5, queueing always 23.3.)
+// With boxes or triangles in the scene every wave of a workgroup owns, behind the staged scene, a queue of
+// (lane, leaf) pairs (QUEUE_ENTRIES x 4 bytes), one 8-byte slot per lane for the closest hit found, and a stack of
+// (lane, level, node) triples.  A node is put there only while fewer than SPREAD_BELOW lanes touch it (more: the
+// wave tests the node's children itself), and stack and queue are worked off whenever they hold a full pass (at
+// most 8 and 16 pairs).  That bounds them: a staged mesh queues only level-1 nodes, 7 left over + 23 new;  for a
+// mesh in global memory, whose nodes of all levels are queued, a pass takes 8 triples off the top and may put 64
+// children there, which the next pass takes first: 30 + 2 x 56 + 64 at most (three levels above the leaves).
+// (Measured on the 292-triangle mesh scene: thresholds of 16, 24 and 40 lanes give the same 20.0 ms, 57 gives
+// 21.5, queueing always 23.3.)
 #ifndef RT_SPREAD_BELOW
 #define RT_SPREAD_BELOW 24
 #endif
-#ifndef RT_NODE_QUEUE_ENTRIES
-#define RT_NODE_QUEUE_ENTRIES 32
-#endif
-constexpr uint32_t QUEUE_ENTRIES = 128u, NODE_QUEUE_ENTRIES = RT_NODE_QUEUE_ENTRIES, SPREAD_BELOW = RT_SPREAD_BELOW;
-static_assert(SPREAD_BELOW - 1u + 7u < NODE_QUEUE_ENTRIES, "the node queue must hold a node's lanes on top of an unfinished pass");
-constexpr uint32_t WAVE_LDS_WORDS = (QUEUE_ENTRIES * 4u + 64u * 8u + NODE_QUEUE_ENTRIES * 4u) / 16u;
+constexpr uint32_t QUEUE_ENTRIES = 128u, SPREAD_BELOW = RT_SPREAD_BELOW;
+constexpr uint32_t NODE_STACK_STAGED = 32u, NODE_STACK_GLOBAL = 256u;
+static_assert(SPREAD_BELOW - 1u + 7u < NODE_STACK_STAGED && SPREAD_BELOW - 1u + 7u + 2u * 56u + 64u <= NODE_STACK_GLOBAL, "stack bounds");
+constexpr uint32_t WAVE_LDS_WORDS = (QUEUE_ENTRIES * 4u + 64u * 8u + NODE_STACK_STAGED * 4u) / 16u;
+constexpr uint32_t WAVE_LDS_WORDS_GLOBAL = (QUEUE_ENTRIES * 4u + 64u * 8u + NODE_STACK_GLOBAL * 4u) / 16u;
 constexpr uint32_t LDS_WAVE_WORDS_PER_GROUP = (BLOCK / 64) * WAVE_LDS_WORDS;
+constexpr uint32_t LDS_WAVE_WORDS_PER_GROUP_GLOBAL = (BLOCK / 64) * WAVE_LDS_WORDS_GLOBAL;
 
 }  // namespace rtd

@@ -552,9 +552,9 @@ void trace_kernel(const TraceParams P,
     const uint32_t n_chunks = L.n_sph_pad >> 2, n_box = L.n_box, n_shapes = L.n_shapes;
     // Behind the staged scene every wave has a queue of (lane, leaf) pairs waiting for their triangle tests and
     // one slot per lane for the closest triangle those tests found.
-    uint32_t* const queue = reinterpret_cast<uint32_t*>(lds + L.lds_words + (tid >> 6) * WAVE_LDS_WORDS);
+    uint32_t* const queue = reinterpret_cast<uint32_t*>(lds + L.lds_words + (tid >> 6) * (TRI_GLOBAL ? WAVE_LDS_WORDS_GLOBAL : WAVE_LDS_WORDS));
     unsigned long long* const found = reinterpret_cast<unsigned long long*>(queue + QUEUE_ENTRIES);
-    uint32_t* const node_queue = queue + QUEUE_ENTRIES + 128u;              // (lane, level-1 node) pairs, NODE_QUEUE_ENTRIES
+    uint32_t* const node_stack = queue + QUEUE_ENTRIES + 128u;              // (lane, level, node) triples
     constexpr unsigned long long NOTHING = ~0ull;
     if (HAS_TRI) found[lane] = NOTHING;
     // The bounds assume a unit direction; the as-written fuzzy metal leaves it unnormalised.
@@ -698,16 +698,29 @@ void trace_kernel(const TraceParams P,
                 q_len += (uint32_t)__popcll(touching);
                 while (q_len >= per_pass) { pass(per_pass); q_head += per_pass; q_len -= per_pass; }
             };
-            // The same one level up: eight lanes per queued (lane, level-1 node) pair, one per leaf of the node,
-            // test the leaf's bound against the pair's ray.
+            // The same further up: a node that few lanes touch is put on the wave's stack as (lane, level, node), and a
+            // pass gives eight lanes to each pair on top of the stack, one per child: they test the child's bound
+            // against the pair's ray.  A touched leaf goes to the triangle queue, a touched inner node back onto the
+            // stack, where the next pass finds it first — depth first, which bounds the stack (see rt_device.h).
+            // A staged mesh is small: only its level-1 nodes are worth queueing.
+            constexpr bool DEEP = TRI_GLOBAL;
             const uint32_t node_pass = n_live >> 3;               // pairs one pass takes
-            uint32_t nq_head = 0u, nq_len = 0u;
+            uint32_t ns_len = 0u;                                  // wave-uniform
+            auto push_nodes = [&](bool touch, uint32_t src, uint32_t level, uint32_t node) {
+                const unsigned long long touching = __ballot(touch);
+                const uint32_t at = ns_len +
+                    __builtin_amdgcn_mbcnt_hi((uint32_t)(touching >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching, 0u));
+                if (touch) node_stack[at] = (src << 26) | (level << 24) | node;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                ns_len += (uint32_t)__popcll(touching);
+            };
             auto bound_pass = [&](uint32_t count) {
                 const uint32_t e = lane_rank >> 3, c = lane_rank & 7u;
                 const bool work = e < count;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t ent = work ? node_queue[(nq_head + e) & (NODE_QUEUE_ENTRIES - 1u)] : (lane << 24);
-                const uint32_t src = ent >> 24, i0 = TREE_FAN * (ent & 0xffffffu) + c;
+                const uint32_t ent = work ? node_stack[ns_len - count + e] : ((lane << 26) | (1u << 24));
+                ns_len -= count;                                   // popped: what the pass pushes may take their place
+                const uint32_t src = ent >> 26, level = DEEP ? (ent >> 24) & 3u : 1u, child = TREE_FAN * (ent & 0xffffffu) + c;
                 const int from = (int)(src << 2);
                 const V3 ro = v3(__uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(o.x))),
                                  __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(o.y))),
@@ -716,36 +729,42 @@ void trace_kernel(const TraceParams P,
                                  __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(d.y))),
                                  __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(d.z))));
                 const uint32_t rkey = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)best.key);
-                const bool valid = work && i0 < L.node_n[0];
-                const bool touch = valid && bound_hit<SEM>(node0[valid ? i0 : 0u], ro, rd, rkey);
+                // the children live one level down
+                const uint32_t n_children = level == 1u ? L.node_n[0] : (level == 2u ? L.node_n[1] : L.node_n[2]);
+                const uint32_t children_at = level == 1u ? L.node_off[0] : (level == 2u ? L.node_off[1] : L.node_off[2]);
+                const bool valid = work && child < n_children;
+                const bool touch = valid && bound_hit<SEM>(nodes[children_at + (valid ? child : 0u)], ro, rd, rkey);
                 if (STATS && valid) ++n_node;
-                push_leaves(touch, src, i0);
+                if (DEEP) push_nodes(touch && level != 1u, src, level - 1u, child);
+                push_leaves(touch && level == 1u, src, child);
+            };
+            // -> the node was put on the stack (few lanes touch it) and full passes were run
+            auto queue_node = [&](bool touch, uint32_t n_touching, uint32_t level, uint32_t node) -> bool {
+                if (!spread || n_touching >= SPREAD_BELOW) return false;
+                push_nodes(touch, lane, level, node);
+                while (ns_len >= node_pass) bound_pass(node_pass);
+                return true;
             };
             for (uint32_t i3 = 0; i3 < L.node_n[3]; ++i3) {
                 if (STATS) ++n_node;
-                if (cull && !__any(bound_hit<SEM>(node3[i3], o, d, best.key))) continue;
+                const bool touch3 = !cull || bound_hit<SEM>(node3[i3], o, d, best.key);
+                const unsigned long long touching3 = __ballot(touch3);
+                if (touching3 == 0ull) continue;
+                if (DEEP && queue_node(touch3, (uint32_t)__popcll(touching3), 3u, i3)) continue;
                 const uint32_t e2 = min(TREE_FAN * i3 + TREE_FAN, L.node_n[2]);
                 for (uint32_t i2 = TREE_FAN * i3; i2 < e2; ++i2) {
                     if (STATS) ++n_node;
-                    if (cull && !__any(bound_hit<SEM>(node2[i2], o, d, best.key))) continue;
+                    const bool touch2 = !cull || bound_hit<SEM>(node2[i2], o, d, best.key);
+                    const unsigned long long touching2 = __ballot(touch2);
+                    if (touching2 == 0ull) continue;
+                    if (DEEP && queue_node(touch2, (uint32_t)__popcll(touching2), 2u, i2)) continue;
                     const uint32_t e1 = min(TREE_FAN * i2 + TREE_FAN, L.node_n[1]);
                     for (uint32_t i1 = TREE_FAN * i2; i1 < e1; ++i1) {
                         if (STATS) ++n_node;
                         const bool touch1 = !cull || bound_hit<SEM>(node1[i1], o, d, best.key);
                         const unsigned long long touching1 = __ballot(touch1);
                         if (touching1 == 0ull) continue;
-                        const uint32_t n_touching1 = (uint32_t)__popcll(touching1);
-                        if (spread && n_touching1 < SPREAD_BELOW) {
-                            // Few lanes are interested in this node: rather than have the whole wave test each of
-                            // its leaves' bounds, queue (lane, node); a pass tests eight leaves' bounds per pair.
-                            const uint32_t at = nq_head + nq_len +
-                                __builtin_amdgcn_mbcnt_hi((uint32_t)(touching1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching1, 0u));
-                            if (touch1) node_queue[at & (NODE_QUEUE_ENTRIES - 1u)] = (lane << 24) | i1;
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                            nq_len += n_touching1;
-                            while (nq_len >= node_pass) { bound_pass(node_pass); nq_head += node_pass; nq_len -= node_pass; }
-                            continue;
-                        }
+                        if (queue_node(touch1, (uint32_t)__popcll(touching1), 1u, i1)) continue;
                         const uint32_t e0 = min(TREE_FAN * i1 + TREE_FAN, L.node_n[0]);
                         for (uint32_t i0 = TREE_FAN * i1; i0 < e0; ++i0) {
                             if (STATS) ++n_node;
@@ -769,7 +788,7 @@ void trace_kernel(const TraceParams P,
                 }
             }
             if (spread) {
-                while (nq_len != 0u) { const uint32_t c = min(nq_len, node_pass); bound_pass(c); nq_head += c; nq_len -= c; }
+                while (ns_len != 0u) bound_pass(min(ns_len, node_pass));
                 while (q_len != 0u) { const uint32_t c = min(q_len, per_pass); pass(c); q_head += c; q_len -= c; }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const unsigned long long f = found[lane];
@@ -1156,7 +1175,7 @@ hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams
     const dim3 grid(n_workgroups * (4u / P.group_waves));
     const float4* b = static_cast<const float4*>(blob);
     const int tri_mode = P.scene.n_tris == 0 ? (P.scene.n_box != 0 ? 1 : 0) : (P.scene.tri_in_lds ? 1 : 2);
-    const size_t lds_bytes = ((size_t)P.scene.lds_words + (tri_mode ? LDS_WAVE_WORDS_PER_GROUP : 0u)) * 16u;
+    const size_t lds_bytes = ((size_t)P.scene.lds_words + (tri_mode == 2 ? LDS_WAVE_WORDS_PER_GROUP_GLOBAL : tri_mode ? LDS_WAVE_WORDS_PER_GROUP : 0u)) * 16u;
     const int geo = tri_mode | (((sem == 0 && P.scene.n_cube != 0) || P.scene.has_glass || P.scene.tcol_off != 0) ? 4 : 0) | (P.rng_mode ? 8 : 0);
 #define RT_CASE(S, G, M) if (sem == S && geo == G && mode == M) return launch_one<S, G, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm, tile_order, tile_cost)
 #define RT_CASES(S, G) RT_CASE(S, G, 0); RT_CASE(S, G, 1); RT_CASE(S, G, 2)
