@@ -12,13 +12,17 @@
 // bounce: lanes never wait for the longest path of a sample.
 //
 // Scene data: every workgroup first copies the scene blob (rt_device.h) into
-// LDS.  The closest-hit loops read it from there with wave-uniform addresses
-// (every lane tests the same primitive at the same time; identical LDS
-// addresses broadcast), which puts the primitive in VECTOR registers: on this
-// chip a vector instruction with a scalar-register operand issues at half the
-// rate of one whose operands are all vector registers, so the scene is kept
-// out of the scalar file on purpose.  The record of the primitive a lane
-// finally hit is gathered per lane, also from LDS.
+// LDS.  Spheres are tested by the whole wave at once: every lane tests the same
+// sphere at the same time, reading it from LDS with a wave-uniform address
+// (identical addresses broadcast), which puts the primitive in VECTOR registers:
+// on this chip a vector instruction with a scalar-register operand issues at
+// half the rate of one whose operands are all vector registers, so the scene is
+// kept out of the scalar file on purpose.  Boxes and triangles are different:
+// a given box or leaf of the mesh concerns only the few lanes whose rays come
+// near it, so those lanes queue (lane, primitive) pairs in LDS and the wave
+// then tests the queued pairs side by side, one or a few lanes per pair — see
+// the tree walk in trace_kernel.  The record of the primitive a lane finally
+// hit is gathered per lane, also from LDS.
 //
 // Arithmetic: binary32 throughout, compiled with -ffp-contract=off.  Every
 // fused multiply-add is an explicit __builtin_fmaf; sqrt is correctly rounded
