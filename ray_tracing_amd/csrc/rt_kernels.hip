@@ -426,7 +426,7 @@ void trace_kernel(const TraceParams P,
 {
     constexpr bool STATS = MODE == 1, TRACE = MODE == 2;
     constexpr bool COST_CLOCK = RT_COST_CLOCK != 0;        // a tile's cost: shader clocks of its slowest wave, not loop iterations
-    constexpr bool HAS_TRI = (GEO & 3) != 0, TRI_GLOBAL = (GEO & 3) == 2, SPREAD_BOXES = HAS_TRI, HAS_CUBE = SEM == 0 && (GEO & 4) != 0, HAS_GLASS = (GEO & 4) != 0, HAS_TCOL = (GEO & 4) != 0, RNG_GLSL = (GEO & 8) != 0;
+    constexpr bool HAS_QUEUES = (GEO & 3) != 0, TRI_GLOBAL = (GEO & 3) == 2, SPREAD_BOXES = HAS_QUEUES, HAS_CUBE = SEM == 0 && (GEO & 4) != 0, HAS_GLASS = (GEO & 4) != 0, HAS_TCOL = (GEO & 4) != 0, RNG_GLSL = (GEO & 8) != 0;
     extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -554,13 +554,13 @@ void trace_kernel(const TraceParams P,
     const float4* const node2 = nodes + L.node_off[2];
     const float4* const node3 = nodes + L.node_off[3];
     const uint32_t n_chunks = L.n_sph_pad >> 2, n_box = L.n_box, n_shapes = L.n_shapes;
-    // Behind the staged scene every wave has a queue of (lane, leaf) pairs waiting for their triangle tests and
-    // one slot per lane for the closest triangle those tests found.
+    // Behind the staged scene every wave has a queue of (lane, leaf) or (lane, box) pairs waiting for their tests,
+    // one slot per lane for the closest hit those tests found, and a stack of tree nodes (rt_device.h).
     uint32_t* const queue = reinterpret_cast<uint32_t*>(lds + L.lds_words + (tid >> 6) * (TRI_GLOBAL ? WAVE_LDS_WORDS_GLOBAL : WAVE_LDS_WORDS));
     unsigned long long* const found = reinterpret_cast<unsigned long long*>(queue + QUEUE_ENTRIES);
     uint32_t* const node_stack = queue + QUEUE_ENTRIES + 128u;              // (lane, level, node) triples
     constexpr unsigned long long NOTHING = ~0ull;
-    if (HAS_TRI) found[lane] = NOTHING;
+    if (HAS_QUEUES) found[lane] = NOTHING;
     // The bounds assume a unit direction; the as-written fuzzy metal leaves it unnormalised.
     const bool cull = (P.flags & 1u) == 0u;
     constexpr uint32_t NONE = 0xffffffffu;
@@ -589,14 +589,14 @@ void trace_kernel(const TraceParams P,
         }
         // The lanes still tracing, and this lane's place among them: they share the queued tests.
         uint32_t n_live = 64u, lane_rank = lane;
-        if (HAS_TRI) {
+        if (HAS_QUEUES) {
             const unsigned long long live = __ballot(1);
             n_live = (uint32_t)__popcll(live);
             lane_rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
         }
-        const bool spread = HAS_TRI && n_live >= 16u;             // fewer live lanes: every test as a wave
+        const bool spread = HAS_QUEUES && n_live >= 16u;             // fewer live lanes: every test as a wave
         // Boxes.  The full test is long (three reciprocals, three candidate points); a lane needs it only for a box
-        // whose bounding sphere its ray touches.  Those (lane, box) pairs are queued and tested one lane per pair.
+        // whose bounds its ray touches (a slab test).  Those (lane, box) pairs are queued and tested one lane per pair.
         if (SPREAD_BOXES && spread && cull) {
             uint32_t bq_len = 0u;                                 // wave-uniform
             // 1 / d for the slab test of the bounds: hardware reciprocals (within an ulp; a zero component gives an
@@ -665,7 +665,7 @@ void trace_kernel(const TraceParams P,
         // triangle, each fetching the ray of the pair's lane across the wave.  A crossing goes to the slot of the
         // ray's lane by an atomic minimum on (key, id) — the same order-independent minimum as everywhere else —
         // and every lane folds its slot into its closest hit when the walk is over.
-        if (HAS_TRI) {
+        if (HAS_QUEUES) {
             const uint32_t per_pass = n_live / TREE_LEAF;         // pairs one pass takes: TREE_LEAF lanes each
             uint32_t q_head = 0u, q_len = 0u;                     // wave-uniform
             auto pass = [&](uint32_t count) {
