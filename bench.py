@@ -67,6 +67,14 @@ def cpu_baseline(cfg, target_seconds=12.0, gpu_render=None):
     out = {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
            "sample": f"{frames} frame(s) of {cfg.width}x{cfg.height}, {spp} of {cfg.spp} spp, depth {cfg.max_depth}, "
                      f"same scene and seed; {dt:.1f} s on {threads} threads"}
+    # The reference's own loop, std::for_each(par_unseq) (rayTracer.h:81), runs on one thread without TBB: one thread too.
+    p1 = orc.params(cfg.width, cfg.height, max(1, spp * frames // (4 * threads)), cfg.max_depth, seed=cfg.seed, semantics=cfg.semantics,
+                    sample_mode=cfg.sample_mode, flags=cfg.flags, triangle_albedo=cfg.triangle_albedo, threads=1)
+    t0 = time.perf_counter()
+    orc.render(cfg.shapes, cfg.triangles, cfg.camera, p1)
+    dt1 = time.perf_counter() - t0
+    out["one_thread"] = {"value": round(cfg.width * cfg.height * p1.spp / dt1 / 1e6, 3), "unit": "Msamples/s",
+                         "sample": f"1 frame of {cfg.width}x{cfg.height}, {p1.spp} spp; {dt1:.1f} s"}
     if gpu_render is not None:
         import numpy as np
         got = gpu_render(spp)
