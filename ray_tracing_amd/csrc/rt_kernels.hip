@@ -624,7 +624,9 @@ void trace_kernel(const TraceParams P,
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             };
             for (uint32_t i = 0; i < n_box; ++i) {
-                const bool touch = box_bound_hit<SEM>(box[3u * i], box[3u * i + 2u], o, inv_d, best.key);
+                float4 bc = box[3u * i], bh = box[3u * i + 2u];
+                asm volatile("" : "+v"(bc.w), "+v"(bh.w));                 // whole 16-byte LDS reads: a 12-byte one costs twice the LDS cycles
+                const bool touch = box_bound_hit<SEM>(bc, bh, o, inv_d, best.key);
                 if (STATS) ++n_box_bound;
                 const unsigned long long touching = __ballot(touch);
                 if (touching == 0ull) continue;
@@ -684,7 +686,8 @@ void trace_kernel(const TraceParams P,
                                  __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(d.z))));
                 if (work) {
                     const float4* const t4 = tri + 4u * (TREE_LEAF * leaf + k);
-                    const float4 w0 = t4[0], w1 = t4[1], w2 = t4[2], w3 = t4[3];
+                    float4 w0 = t4[0], w1 = t4[1], w2 = t4[2], w3 = t4[3];
+                    if (!TRI_GLOBAL) asm volatile("" : "+v"(w0.w), "+v"(w2.w), "+v"(w3.w));    // whole 16-byte LDS reads (see the direct path)
                     uint32_t ckey, cid;
                     const bool inside = triangle_candidate<SEM>(w0, w1, w2, w3, n_shapes, ro, rd, ckey, cid);
                     if (inside && ckey < Window<SEM>::far - Window<SEM>::tmin)
