@@ -449,6 +449,7 @@ int rt_upload_triangles(rt_ctx* ctx, const rt_triangle* tris, uint32_t n)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;
     RT_REQUIRE(ctx, n == 0 || tris, "rt_upload_triangles: triangles is NULL");
+    RT_REQUIRE(ctx, n <= (1u << 26) - 4u, "rt_upload_triangles: more than 2^26 triangles (a leaf's number must fit 24 bits)");
     try { ctx->tris.assign(tris, tris + n); } catch (...) { return fail(ctx, RT_ERR_OUT_OF_MEMORY, "rt_upload_triangles: host allocation failed"); }
     ctx->tri_colors.clear();
     ctx->blob_dirty = true;
