@@ -225,7 +225,36 @@ static void build_tree(const std::vector<rt_triangle>& tris, const rtd::SceneLay
                 w.f[0] = w.f[1] = w.f[2] = 0.0f; w.f[3] = std::numeric_limits<float>::infinity();
                 continue;
             }
-            const double c[3] = { 0.5 * (blo[0] + bhi[0]), 0.5 * (blo[1] + bhi[1]), 0.5 * (blo[2] + bhi[2]) };
+            // Centre: that of the bounding box, moved towards the farthest vertex a shrinking step at a time
+            // (Badoiu and Clarkson), which converges on the centre of the smallest enclosing ball; the better of
+            // the two is kept.  Any centre is valid: the radius below is measured from the one chosen.
+            double c[3] = { 0.5 * (blo[0] + bhi[0]), 0.5 * (blo[1] + bhi[1]), 0.5 * (blo[2] + bhi[2]) };
+            {
+                auto radius2 = [&](const double* q_) {
+                    double r2 = 0;
+                    for (uint64_t s_ = first; s_ < last; ++s_)
+                        for (int v = 0; v < 3; ++v) {
+                            double dd = 0;
+                            for (int k = 0; k < 3; ++k) { const double e = g[order[s_]].v[v][k] - q_[k]; dd += e * e; }
+                            r2 = std::max(r2, dd);
+                        }
+                    return r2;
+                };
+                double best_c[3] = { c[0], c[1], c[2] }, best_r2 = radius2(c), m[3] = { c[0], c[1], c[2] };
+                const int steps = (last - first) <= 64 ? 256 : 64;
+                for (int it = 1; it <= steps; ++it) {
+                    double far2 = -1; const double* far_p = nullptr;
+                    for (uint64_t s_ = first; s_ < last; ++s_)
+                        for (int v = 0; v < 3; ++v) {
+                            double dd = 0;
+                            for (int k = 0; k < 3; ++k) { const double e = g[order[s_]].v[v][k] - m[k]; dd += e * e; }
+                            if (dd > far2) { far2 = dd; far_p = g[order[s_]].v[v]; }
+                        }
+                    if (far2 < best_r2) { best_r2 = far2; for (int k = 0; k < 3; ++k) best_c[k] = m[k]; }
+                    for (int k = 0; k < 3; ++k) m[k] += (far_p[k] - m[k]) / (double)(it + 1);
+                }
+                for (int k = 0; k < 3; ++k) c[k] = best_c[k];
+            }
             const float cf[3] = { (float)c[0], (float)c[1], (float)c[2] };
             double r2 = 0;
             for (uint64_t s_ = first; s_ < last; ++s_) {
