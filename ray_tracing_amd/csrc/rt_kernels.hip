@@ -202,10 +202,10 @@ RT_DEV V3 hemisphere_glsl(V3 n, float u1, float u2)
     float dist = sqrt_rn(fma_(-r, r, 1.0f));         // 1 - r*r >= 2^-24
     float x = c * dist, y = s * dist;
     float q = fma_(n.x, n.x, n.y * n.y);          // |(-n.y, n.x, 0)|^2
-    // The length is only compared with 0.01: any tiny value serves for a tiny q.
-    float len_xy = sqrt_rn(q);
+    // length(b1.xy) < 0.01 (:72): the correctly rounded square root is monotonic, so the comparison holds exactly for
+    // q below 0x38d1b716 (9.999999e-05), the first float whose root reaches 0.01f — no root needed.
     V3 b1;
-    if (len_xy < 0.01f) b1 = normalize(v3(0.0f, -n.z, n.y));
+    if (q < __uint_as_float(0x38d1b716u)) b1 = normalize(v3(0.0f, -n.z, n.y));
     else { float inv = rsqrt_nr(q); b1 = v3(-n.y * inv, n.x * inv, 0.0f * inv); }
     V3 b2 = cross(n, b1);
     return v3(fma_(n.x, r, fma_(b2.x, y, b1.x * x)),

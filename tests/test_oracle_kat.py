@@ -437,3 +437,17 @@ def test_floor_under_a_ceiling_light_has_the_closed_form_radiance(rta, orc):
     assert near.sum() > 500
     assert abs(img[near][:, 0].mean() - 0.6 * (1000.0 / 1010.0) ** 2) < 0.006
 
+
+
+def test_tangent_fallback_threshold(orc):
+    """randomOnHalfUnitShere switches its tangent when length((-n.y, n.x)) < 0.01 (RayTracing.glsl:72).  The kernel compares
+    the squared length with the first float whose correctly rounded root reaches 0.01f instead of taking the root."""
+    t = np.float32(0.01)
+    first = np.uint32(0x38d1b716).view(np.float32)
+    assert np.sqrt(first, dtype=np.float32) >= t and np.sqrt(np.nextafter(first, np.float32(0)), dtype=np.float32) < t
+    # both sides of the switch through the oracle: a normal with |n.xy| just below and just above 0.01
+    for nxy, fallback in ((0.0099, True), (0.0101, False)):
+        n = np.array([nxy, 0.0, math.sqrt(1.0 - nxy * nxy)], dtype=np.float32)
+        v = orc.hemisphere_glsl(tuple(float(x) for x in n), 0.0, 0.0)        # angle 0, r 0: the first tangent itself
+        want = np.array([0.0, -n[2], n[1]]) / math.hypot(n[2], n[1]) if fallback else np.array([-n[1], n[0], 0.0]) / math.hypot(n[0], n[1])
+        np.testing.assert_allclose(np.asarray(v, dtype=np.float64), want, atol=2e-6)
