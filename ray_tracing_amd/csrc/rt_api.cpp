@@ -313,7 +313,7 @@ static int build_blob(rt_ctx* ctx)
     const uint32_t wave_words = (n_tris || n_box) ? rtd::LDS_WAVE_WORDS_PER_GROUP : 0u;     // queues and slots of the spread tests
     if ((size_t)(L.node_off[rtd::TREE_LEVELS - 1u] + (n_tris ? rtd::LDS_WAVE_WORDS_PER_GROUP_GLOBAL : wave_words)) * 16u > rtd::LDS_MAX_BYTES)
         return fail(ctx, RT_ERR_INVALID_ARG, "scene: %u shapes need more than the %u-byte LDS stage", n_shapes, rtd::LDS_MAX_BYTES);
-    if ((size_t)(staged_words + wave_words) * 16u <= rtd::LDS_MAX_BYTES) { L.lds_words = staged_words; L.tri_in_lds = 1; }
+    if ((size_t)(staged_words + wave_words) * 16u <= rtd::LDS_MAX_BYTES && !getenv("RT_MESH_IN_GLOBAL")) { L.lds_words = staged_words; L.tri_in_lds = 1; }
     else { L.lds_words = L.node_off[rtd::TREE_LEVELS - 1u]; L.tri_in_lds = 0; }     // the mesh and its tree stay in global memory
     // Per-triangle albedo: read only at a hit, so it stays in global memory behind everything else.
     if (colors) { L.tcol_off = L.total_words; L.total_words += n_tris; }
