@@ -465,3 +465,10 @@ def test_many_boxes_fill_more_than_one_pass(rta, orc):
     st = check_config(rta, orc, cfg)
     assert st["box_tests"] == st["segments"] * 44 and st["box_tests_done"] < st["box_tests"] // 2
 
+
+def test_small_mesh_left_in_global_memory(rta, orc, monkeypatch):
+    """The 292-triangle mesh read from global memory (RT_MESH_IN_GLOBAL, read at upload) instead of staged: the path of a
+    mesh that does not fit, with tree nodes of every level queued."""
+    monkeypatch.setenv("RT_MESH_IN_GLOBAL", "1")
+    check_config(rta, orc, rta.scenes.config3(width=96, height=54, spp=4, max_depth=8))
+
