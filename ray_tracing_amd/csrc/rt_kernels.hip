@@ -631,6 +631,13 @@ void trace_kernel(const TraceParams P,
                 const unsigned long long touching = __ballot(touch);
                 if (touching == 0ull) continue;
                 const uint32_t n_touching = (uint32_t)__popcll(touching);
+                if (2u * n_touching >= n_live) {
+                    // Nearly every lane wants this box (a floor): the wave tests it on the spot, without the queue.
+                    const float4 bx1 = box[3u * i + 1u];
+                    take_if_closer(best, __float_as_uint(hit_box(bc, bx1.y, bx1.z, o, d)) - Window<SEM>::tmin, __float_as_uint(bx1.x));
+                    if (STATS) ++n_box_test;
+                    continue;
+                }
                 if (bq_len + n_touching > n_live) { box_pass(bq_len); bq_len = 0u; }      // a pass takes one pair per live lane
                 const uint32_t at = bq_len + __builtin_amdgcn_mbcnt_hi((uint32_t)(touching >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)touching, 0u));
                 if (touch) queue[at] = (lane << 24) | i;
