@@ -37,7 +37,7 @@ namespace rtd {
 // Bounding-sphere tree: level 0 node i bounds the sorted triangles [TREE_LEAF*i,
 // TREE_LEAF*(i+1)); a node i of level l+1 bounds the nodes [TREE_FAN*i, TREE_FAN*(i+1)) of
 // level l.  Every level is padded to a multiple of TREE_FAN with never-hit nodes (NaN
-// centre).  A node is {centre.xyz, R^2}, R = 1.01 * radius + 1e-4: the slack covers the
+// centre).  A node is {centre.xyz, R}, R = 1.01 * radius + 1e-4 (radius: of a small enclosing ball of the node's vertices): the slack covers the
 // rounding of the triangle test itself, so that a ray the triangle test could accept is
 // never culled (see bound_hit in rt_kernels.hip).
 constexpr uint32_t TREE_LEAF = 4, TREE_FAN = 8, TREE_LEVELS = 4;
