@@ -472,3 +472,37 @@ def test_small_mesh_left_in_global_memory(rta, orc, monkeypatch):
     monkeypatch.setenv("RT_MESH_IN_GLOBAL", "1")
     check_config(rta, orc, rta.scenes.config3(width=96, height=54, spp=4, max_depth=8))
 
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_scenes(rta, orc, seed):
+    """Random mixtures of spheres, boxes and loose triangles with random materials, under both rule sets: the queued
+    tests (pairs from many primitives, partly filled passes, waves with few live lanes) against the exhaustive scan."""
+    from ray_tracing_amd import host, _abi
+    rng = np.random.default_rng(1000 + seed)
+    sem = seed % 2
+
+    def material():
+        kind = rng.integers(0, 5)
+        col = tuple(float(x) for x in rng.uniform(0.2, 1.0, 3))
+        if kind == 0:
+            return host.Light(tuple(float(x) for x in rng.uniform(1.0, 4.0, 3)))
+        if kind == 1:
+            return host.Metal(col, fuzz=float(rng.choice([0.0, 0.2]))) if sem == 0 else host.Metal(col)
+        return host.Lambertian(col)
+
+    def point():
+        return (float(rng.uniform(-3, 5)), float(rng.uniform(0, 4)), float(rng.uniform(-9, -1)))
+
+    objs = [host.Box((0, -50, 0), (100, 1, 1), host.Lambertian((0.5, 0.7, 0.6))), host.Circle((1, 7, -4), 2.5, host.Light((3, 3, 3)))]
+    objs += [host.Circle(point(), float(rng.uniform(0.2, 1.0)), material()) for _ in range(rng.integers(0, 13))]
+    objs += [host.Box(point(), (float(rng.uniform(0.3, 1.5)),) * 3, material()) for _ in range(rng.integers(0, 13))]
+    tris = []
+    for _ in range(int(rng.integers(0, 300))):
+        a = np.array(point()); e1 = rng.uniform(-0.6, 0.6, 3); e2 = rng.uniform(-0.6, 0.6, 3)
+        tris.append(host.SimpleTriangle(tuple(a), tuple(a + e1), tuple(a + e2)))
+    w, h = int(rng.integers(20, 100)), int(rng.integers(10, 60))
+    cfg = rta.scenes.SceneConfig(f"random{seed}", host.pack(objs, _abi.SHAPE_DTYPE),
+                                 host.pack(tris, _abi.TRIANGLE_DTYPE) if tris else np.zeros(0, dtype=_abi.TRIANGLE_DTYPE),
+                                 host.Camera(w, h, 1.0, (1, 1, 6)).data.copy(), w, h, 3, 5, sem, seed=seed + 1)
+    check_config(rta, orc, cfg, trace_samples=(0, 2))
+
