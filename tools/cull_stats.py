@@ -1,4 +1,7 @@
-import sys; sys.path.insert(0,'/root/repo')
+"""Triangle and bound tests per ray segment that the kernels execute on the two meshes, beside the exhaustive scan's.
+usage: python tools/cull_stats.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ray_tracing_amd as rta
 for mesh in ("Bunny-LowPoly.off","bunny.off"):
     cfg = rta.scenes.config3(width=480, height=270, spp=16, max_depth=10, mesh=mesh)

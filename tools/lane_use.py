@@ -1,3 +1,5 @@
+"""Segments per sample and the share of lanes at work per wave iteration, per configuration.
+usage: python tools/lane_use.py [c1 c2 ...]"""
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ray_tracing_amd as rta
 for name in sys.argv[1:] or ["c2", "c3", "c5"]:
