@@ -184,10 +184,36 @@ static void build_tree(const std::vector<rt_triangle>& tris, const rtd::SceneLay
         if (h == 0u || h >= len) h = len / 2u;
         double blo[3] = { 1e300, 1e300, 1e300 }, bhi[3] = { -1e300, -1e300, -1e300 };
         for (uint32_t i = r.lo; i < r.hi; ++i) for (int k = 0; k < 3; ++k) { blo[k] = std::min(blo[k], g[order[i]].c[k]); bhi[k] = std::max(bhi[k], g[order[i]].c[k]); }
+        // Split along the axis whose two halves are the most compact: the sum, over the halves, of triangle count
+        // times the squared half diagonal of the box around the half's vertices (what a ray's chance of touching
+        // the half's bound grows with).  Ranges of more than 4 096 triangles take the longest axis of the
+        // centroids' extent without trying all three.
         int ax = 0;
         if (bhi[1] - blo[1] > bhi[ax] - blo[ax]) ax = 1;
         if (bhi[2] - blo[2] > bhi[ax] - blo[ax]) ax = 2;
-        std::stable_sort(order.begin() + r.lo, order.begin() + r.hi, [&](uint32_t x, uint32_t y) { return g[x].c[ax] < g[y].c[ax]; });
+        auto sort_along = [&](int a) {
+            std::stable_sort(order.begin() + r.lo, order.begin() + r.hi, [&](uint32_t x, uint32_t y) { return g[x].c[a] < g[y].c[a]; });
+        };
+        if (len <= 4096u) {
+            double best_cost = 1e300;
+            int best_ax = ax;
+            for (int a = 0; a < 3; ++a) {
+                sort_along(a);
+                double cost = 0;
+                for (int half = 0; half < 2; ++half) {
+                    const uint32_t b0 = half ? r.lo + h : r.lo, b1 = half ? r.hi : r.lo + h;
+                    double lo3[3] = { 1e300, 1e300, 1e300 }, hi3[3] = { -1e300, -1e300, -1e300 };
+                    for (uint32_t i = b0; i < b1; ++i)
+                        for (int v = 0; v < 3; ++v) for (int k = 0; k < 3; ++k) { lo3[k] = std::min(lo3[k], g[order[i]].v[v][k]); hi3[k] = std::max(hi3[k], g[order[i]].v[v][k]); }
+                    double d2 = 0;
+                    for (int k = 0; k < 3; ++k) d2 += 0.25 * (hi3[k] - lo3[k]) * (hi3[k] - lo3[k]);
+                    cost += d2 * (double)(b1 - b0);
+                }
+                if (cost < best_cost) { best_cost = cost; best_ax = a; }
+            }
+            ax = best_ax;
+        }
+        sort_along(ax);
         todo.push_back({ r.lo, r.lo + h });
         todo.push_back({ r.lo + h, r.hi });
     }
