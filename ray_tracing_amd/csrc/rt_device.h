@@ -100,7 +100,14 @@ constexpr uint32_t LDS_MAX_BYTES = 64u * 1024u;
 #endif
 constexpr uint32_t QUEUE_ENTRIES = 128u, SPREAD_BELOW = RT_SPREAD_BELOW;
 constexpr uint32_t NODE_STACK_STAGED = 32u, NODE_STACK_GLOBAL = 256u;
-static_assert(SPREAD_BELOW - 1u + 7u < NODE_STACK_STAGED && SPREAD_BELOW - 1u + 7u + 2u * 56u + 64u <= NODE_STACK_GLOBAL, "stack bounds");
+// What is left below a full pass, plus what one step can add, must fit (64 lanes; a pass takes 64 / TREE_LEAF pairs
+// or 64 / TREE_FAN triples and can put 64 new ones there; three levels above the leaves).
+static_assert(TREE_LEAF >= 1u && TREE_LEAF <= 64u && TREE_FAN >= 2u && TREE_FAN <= 64u && SPREAD_BELOW <= 64u, "tree shape");
+static_assert((64u / TREE_LEAF - 1u) + 64u <= QUEUE_ENTRIES, "the leaf queue overflows");
+static_assert((64u / TREE_FAN - 1u) + (SPREAD_BELOW - 1u) <= NODE_STACK_STAGED, "the node stack of a staged mesh overflows");
+static_assert((64u / TREE_FAN - 1u) + (SPREAD_BELOW - 1u) + (TREE_LEVELS - 2u) * (64u - 64u / TREE_FAN) + 64u <= NODE_STACK_GLOBAL,
+              "the node stack of a mesh in global memory overflows");
+static_assert(TREE_LEVELS == 4u, "stack entries carry two bits of level, the walk has four nested loops");
 constexpr uint32_t WAVE_LDS_WORDS = (QUEUE_ENTRIES * 4u + 64u * 8u + NODE_STACK_STAGED * 4u) / 16u;
 constexpr uint32_t WAVE_LDS_WORDS_GLOBAL = (QUEUE_ENTRIES * 4u + 64u * 8u + NODE_STACK_GLOBAL * 4u) / 16u;
 constexpr uint32_t LDS_WAVE_WORDS_PER_GROUP = (BLOCK / 64) * WAVE_LDS_WORDS;

@@ -718,7 +718,7 @@ void trace_kernel(const TraceParams P,
             // stack, where the next pass finds it first — depth first, which bounds the stack (see rt_device.h).
             // A staged mesh is small: only its level-1 nodes are worth queueing.
             constexpr bool DEEP = TRI_GLOBAL;
-            const uint32_t node_pass = n_live >> 3;               // pairs one pass takes
+            const uint32_t node_pass = n_live / TREE_FAN;         // triples one pass takes: TREE_FAN lanes each
             uint32_t ns_len = 0u;                                  // wave-uniform
             auto push_nodes = [&](bool touch, uint32_t src, uint32_t level, uint32_t node) {
                 const unsigned long long touching = __ballot(touch);
@@ -729,7 +729,7 @@ void trace_kernel(const TraceParams P,
                 ns_len += (uint32_t)__popcll(touching);
             };
             auto bound_pass = [&](uint32_t count) {
-                const uint32_t e = lane_rank >> 3, c = lane_rank & 7u;
+                const uint32_t e = lane_rank / TREE_FAN, c = lane_rank % TREE_FAN;
                 const bool work = e < count;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const uint32_t ent = work ? node_stack[ns_len - count + e] : ((lane << 26) | (1u << 24));
