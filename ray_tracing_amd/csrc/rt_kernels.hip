@@ -414,7 +414,8 @@ template <int SEM, int GEO, int MODE>
 __global__ __launch_bounds__(BLOCK)
 // Spheres only: 64 registers, eight waves per SIMD.  With boxes or a mesh the staged scene and the wave's queues
 // leave room for six workgroups per CU at most, so those instances may use the registers of six waves per SIMD.
-__attribute__((amdgpu_waves_per_eu((GEO & 3) != 0 ? 6 : 8, 8)))
+// Sphere scenes with dielectrics, cubes or triangle colours need a few registers more than 64: seven waves, no spills.
+__attribute__((amdgpu_waves_per_eu((GEO & 3) != 0 ? 6 : ((GEO & 4) != 0 ? 7 : 8), 8)))
 void trace_kernel(const TraceParams P,
                   const float4* __restrict__ blob,
                   uint32_t* __restrict__ accum,
