@@ -44,13 +44,43 @@ def algorithmic_flops(st, executed=True):
             st["diffuse"] * F_DIFFUSE + st["specular"] * F_SPECULAR + st["terminal"] * F_TERMINAL)
 
 
+def host_threads():
+    """Threads this process may use: its CPU affinity, capped by OMP_NUM_THREADS when the environment sets one (a
+    GPU box gives a one-GPU job a share of the machine, not all of it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        n = min(n, int(os.environ["OMP_NUM_THREADS"]))
+    except (KeyError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def kernel_source_sha():
+    """Identifies the kernel sources a profile was taken with."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("rt_kernels.hip", "rt_device.h"):
+        h.update(open(os.path.join(ROOT, "ray_tracing_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(cfg, target_seconds=12.0, gpu_render=None):
     """The CPU oracle (a restatement of the reference's tracer; the reference itself cannot be built
     here) timed on this host on a bounded sample of the same workload.  The frame it produces is
     also compared, word for word, with the GPU's frame of the same samples (gpu_render(spp) ->
     accumulator words): the PSNR of the headline metric."""
     from oracle import oracle as orc
-    threads = max(1, min(16, os.cpu_count() or 1))
+    threads = host_threads()
     p = orc.params(cfg.width, cfg.height, 1, cfg.max_depth, seed=cfg.seed, semantics=cfg.semantics,
                    sample_mode=cfg.sample_mode, flags=cfg.flags, triangle_albedo=cfg.triangle_albedo, threads=threads)
     t0 = time.perf_counter()
@@ -65,6 +95,7 @@ def cpu_baseline(cfg, target_seconds=12.0, gpu_render=None):
     dt = time.perf_counter() - t0
     n = cfg.width * cfg.height * spp * frames
     out = {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
+           "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
            "sample": f"{frames} frame(s) of {cfg.width}x{cfg.height}, {spp} of {cfg.spp} spp, depth {cfg.max_depth}, "
                      f"same scene and seed; {dt:.1f} s on {threads} threads"}
     # The reference's own loop, std::for_each(par_unseq) (rayTracer.h:81), runs on one thread without TBB: one thread too.
@@ -194,6 +225,21 @@ def main():
     stats = rts[0].render(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, first_sample=shard.first_sample, stats=True)
 
     say("stats launch done")
+    # A one-shot call: a fresh context (no plan learned from an earlier frame), one render of the whole workload,
+    # waited for.  The process has run the kernel before (the stats launch), so its code is loaded.
+    cold_ms = None
+    if world == 1:
+        rt_cold = rta.scenes.make_renderer(cfg, device=local_rank)
+        rt_cold.setStream(torch.cuda.current_stream().cuda_stream)
+        accums[0].zero_()
+        rt_cold.bindAccum(accums[0].data_ptr(), cfg.width, cfg.height)
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        rt_cold.render(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, first_sample=shard.first_sample)
+        torch.cuda.synchronize()
+        cold_ms = (time.perf_counter() - tc) * 1e3
+        rt_cold.bindAccum(None, 0, 0)
+        rt_cold.close()
     run(args.warmup)
     say("warmup done")
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -230,12 +276,17 @@ def main():
         achieved = flops / (kernel_ms * 1e-3) / 1e12
         # Counters of the same launch from the committed rocprofv3 passes (profiles/traffic.json): HBM bytes, and
         # the vector instructions issued, which price the launch in issue slots of the vector pipe.
-        traffic, issue = None, None
+        traffic, issue, traffic_note = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath)).get(f"{args.config}_{cfg.width}x{cfg.height}_{shard.spp}spp", {}) if not args.mesh else {}
                 traffic = tj.get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic_note = {"source": "replayed from " + str(tj.get("source", "profiles/")) + " (rocprofv3 --pmc passes of this "
+                                              "command; not measured in this run)",
+                                    "profiled_kernel_sha": tj.get("kernel_sha"), "kernel_sha": kernel_source_sha(),
+                                    "traffic_stale": tj.get("kernel_sha") != kernel_source_sha()}
                 if tj.get("valu_instructions_per_launch"):
                     n_inst = tj["valu_instructions_per_launch"]
                     cyc = kernel_ms * 1e-3 * PEAK_CLOCK_HZ * N_SIMD / n_inst
@@ -259,8 +310,9 @@ def main():
                        "shard": args.shard, "spp_total": parallel.total_samples(shard), "device": info["name"]},
             "mrays_per_s": round(stats["segments"] * world / (elapsed / args.steps) / 1e6, 2),
             "segments_per_sample": round(stats["segments"] / max(1, stats["samples"]), 4),
+            "cold_first_frame_ms": None if cold_ms is None else round(cold_ms, 4),
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "trace_kernel", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_flops_per_launch": flops,
                          "exhaustive_scan_flops_per_launch": algorithmic_flops(stats, executed=False),

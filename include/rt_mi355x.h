@@ -195,6 +195,12 @@ int rt_upload_triangles(rt_ctx* ctx, const rt_triangle* triangles, uint32_t n);
  * to the single colour, and so does every rt_upload_triangles. */
 int rt_upload_triangle_colors(rt_ctx* ctx, const float* rgb, uint32_t n);
 
+/* The uploads above only record the arrays (and refuse a scene that cannot be laid out); the
+ * device copy — with the tree over the triangles, the expensive part — is built once, by the
+ * first render call after them, or here.  updateShapeBuffer() of the reference uploads shapes and
+ * triangles one after the other (ray_tracing_compute_shader.h:44-57): one build for both. */
+int rt_commit_scene(rt_ctx* ctx);
+
 /* Replaces RayTracingComputeShader::updateCameraBuffer
  * (ray_tracing_compute_shader.h:34-37): 21 floats, Camera::data. */
 int rt_set_camera(rt_ctx* ctx, const float data[RT_CAMERA_FLOATS]);
@@ -223,7 +229,10 @@ int rt_bind_accum(rt_ctx* ctx, void* device_words, uint32_t width, uint32_t heig
  * rayTracer.h:78,113 traces steps + 1 = 11).  seed replaces the wall-clock
  * `time` uniform.  For the grid sample modes grid_n * grid_n samples make one
  * pixel; pass 0 to derive grid_n from first_sample + spp (must be a square).
- * Asynchronous on the context's stream. */
+ * Asynchronous on the context's stream.
+ * Workgroups are handed tiles by a plan made from what the tiles cost in the previous call of the
+ * same frame size; a call of 64 or more samples per pixel that has no plan yet makes one from its
+ * own first 16 samples.  Any plan gives the same words. */
 int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp,
               uint32_t max_depth, uint64_t seed, uint32_t first_sample,
               uint32_t grid_n);

@@ -62,6 +62,7 @@ SIGNATURES = {
     "rt_set_camera": (_int, [_vp, _fp]),
     "rt_set_row_shard": (_int, [_vp, _u32, _u32, _u32]),
     "rt_bind_accum": (_int, [_vp, _vp, _u32, _u32]),
+    "rt_commit_scene": (_int, [_vp]),
     "rt_render": (_int, [_vp, _u32, _u32, _u32, _u32, _u64, _u32, _u32]),
     "rt_render_stats": (_int, [_vp, _u32, _u32, _u32, _u32, _u64, _u32, _u32, C.POINTER(Stats)]),
     "rt_render_timeline": (_int, [_vp, _u32, _u32, _u32, _u32, _u64, _u32, _u32, C.POINTER(Stats), _vp, _u32]),

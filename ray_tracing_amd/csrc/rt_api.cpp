@@ -77,6 +77,11 @@ struct rt_ctx {
     uint32_t plan_units = 0;             // workgroups of the planned launch
 
     int compute_units = 0;
+
+    // Staging for entry points that return data to host memory (rt_resolve, rt_trace_debug): grown on demand, kept.
+    void* d_stage = nullptr;             size_t stage_cap = 0;
+    // Switches for measurements, read from the environment once, when the context is created.
+    bool env_group_waves_1 = false, env_no_tile_order = false, env_no_slices = false, env_mesh_in_global = false, env_no_probe = false;
 };
 
 static thread_local std::string g_create_error;
@@ -298,11 +303,11 @@ static void build_tree(const std::vector<rt_triangle>& tris, const rtd::SceneLay
     }
 }
 
-// Repack the uploaded arrays into the blob the kernels read (layout: rt_device.h)
-// and copy it to the device.
-static int build_blob(rt_ctx* ctx)
+// Where everything goes in the blob (layout: rt_device.h) for the arrays uploaded so far; fails when the part that
+// must be staged does not fit.  Cheap: run at every upload, so that a scene that cannot be rendered is refused there.
+struct BlobPlan { rtd::SceneLayout L; uint32_t node_pad[rtd::TREE_LEVELS]; uint32_t n_tri_pad, n_sph, n_box, n_cube; bool colors; };
+static int plan_blob(rt_ctx* ctx, BlobPlan& B)
 {
-    RT_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t n_shapes = (uint32_t)ctx->shapes.size(), n_tris = (uint32_t)ctx->tris.size();
     uint32_t n_sph = 0, n_box = 0, n_cube = 0;
     for (const rt_shape& s : ctx->shapes) {
@@ -317,32 +322,49 @@ static int build_blob(rt_ctx* ctx)
     L.box_off = L.sid_off + L.n_sph_pad / 4u;
     // Bounding-sphere tree over the triangles (rt_device.h).
     const uint32_t n_tri_pad = (n_tris + rtd::TREE_LEAF - 1u) / rtd::TREE_LEAF * rtd::TREE_LEAF;
-    uint32_t node_pad[rtd::TREE_LEVELS];
     {
         uint32_t n = n_tri_pad / rtd::TREE_LEAF;
         for (uint32_t l = 0; l < rtd::TREE_LEVELS; ++l) {
             L.node_n[l] = n;
-            node_pad[l] = (n + rtd::TREE_FAN - 1u) / rtd::TREE_FAN * rtd::TREE_FAN;
+            B.node_pad[l] = (n + rtd::TREE_FAN - 1u) / rtd::TREE_FAN * rtd::TREE_FAN;
             n = (n + rtd::TREE_FAN - 1u) / rtd::TREE_FAN;
         }
         // The top level is scanned linearly, so it is not grouped any further.
     }
     L.cub_off = L.box_off + 3u * n_box;
     uint32_t off = L.cub_off + 4u * n_cube;
-    for (int l = (int)rtd::TREE_LEVELS - 1; l >= 0; --l) { L.node_off[l] = off; off += node_pad[l]; }
+    for (int l = (int)rtd::TREE_LEVELS - 1; l >= 0; --l) { L.node_off[l] = off; off += B.node_pad[l]; }
     L.tri_off = off;
     const uint32_t staged_words = L.tri_off + 4u * n_tri_pad;        // what a workgroup stages when the mesh fits
     // The place of each uploaded triangle in the sorted list is looked up once per hit: it stays in global memory.
     L.inv_off = staged_words;
     L.total_words = L.inv_off + (n_tris + 3u) / 4u;
-    const bool colors = !ctx->tri_colors.empty() && ctx->tri_colors.size() == 3u * (size_t)n_tris;
+    B.colors = !ctx->tri_colors.empty() && ctx->tri_colors.size() == 3u * (size_t)n_tris;
     const uint32_t wave_words = (n_tris || n_box) ? rtd::LDS_WAVE_WORDS_PER_GROUP : 0u;     // queues and slots of the spread tests
     if ((size_t)(L.node_off[rtd::TREE_LEVELS - 1u] + (n_tris ? rtd::LDS_WAVE_WORDS_PER_GROUP_GLOBAL : wave_words)) * 16u > rtd::LDS_MAX_BYTES)
         return fail(ctx, RT_ERR_INVALID_ARG, "scene: %u shapes need more than the %u-byte LDS stage", n_shapes, rtd::LDS_MAX_BYTES);
-    if ((size_t)(staged_words + wave_words) * 16u <= rtd::LDS_MAX_BYTES && !getenv("RT_MESH_IN_GLOBAL")) { L.lds_words = staged_words; L.tri_in_lds = 1; }
+    if ((size_t)(staged_words + wave_words) * 16u <= rtd::LDS_MAX_BYTES && !ctx->env_mesh_in_global) { L.lds_words = staged_words; L.tri_in_lds = 1; }
     else { L.lds_words = L.node_off[rtd::TREE_LEVELS - 1u]; L.tri_in_lds = 0; }     // the mesh and its tree stay in global memory
     // Per-triangle albedo: read only at a hit, so it stays in global memory behind everything else.
-    if (colors) { L.tcol_off = L.total_words; L.total_words += n_tris; }
+    if (B.colors) { L.tcol_off = L.total_words; L.total_words += n_tris; }
+    B.L = L; B.n_tri_pad = n_tri_pad; B.n_sph = n_sph; B.n_box = n_box; B.n_cube = n_cube;
+    return RT_OK;
+}
+
+// Repack the uploaded arrays into the blob the kernels read and copy it to the device.  Runs once per changed
+// scene, at the first render (or rt_commit_scene) after the uploads: updateShapeBuffer() of the reference uploads
+// shapes and triangles one after the other (ray_tracing_compute_shader.h:44-57), and the tree over the triangles
+// is the expensive part.
+static int build_blob_impl(rt_ctx* ctx)
+{
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    BlobPlan B;
+    int prc = plan_blob(ctx, B);
+    if (prc) return prc;
+    rtd::SceneLayout L = B.L;
+    const uint32_t n_shapes = L.n_shapes, n_tris = L.n_tris, n_sph = B.n_sph, n_box = B.n_box, n_tri_pad = B.n_tri_pad;
+    const uint32_t* node_pad = B.node_pad;
+    const bool colors = B.colors;
 
     std::vector<Word> blob(L.total_words ? L.total_words : 1u);
     memset(blob.data(), 0, blob.size() * sizeof(Word));
@@ -429,6 +451,20 @@ static int build_blob(rt_ctx* ctx)
     return RT_OK;
 }
 
+static int build_blob(rt_ctx* ctx)
+{
+    try { return build_blob_impl(ctx); }
+    catch (...) { return fail(ctx, RT_ERR_OUT_OF_MEMORY, "scene upload: host allocation failed"); }
+}
+
+// An upload changed the host arrays: check that the scene can still be laid out; the blob itself is rebuilt later.
+static int scene_changed(rt_ctx* ctx)
+{
+    ctx->blob_dirty = true;
+    BlobPlan B;
+    return plan_blob(ctx, B);
+}
+
 extern "C" {
 
 int rt_create(rt_ctx** out, const rt_config* cfg)
@@ -464,6 +500,12 @@ int rt_create(rt_ctx** out, const rt_config* cfg)
     e = hipGetDeviceProperties(&prop, c.device);
     if (e != hipSuccess) { (void)hipFree(ctx->d_stats); delete ctx; return fail(nullptr, RT_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); }
     ctx->compute_units = prop.multiProcessorCount;
+    auto env_on = [](const char* name) { const char* v = getenv(name); return v && *v && strcmp(v, "0") != 0; };
+    ctx->env_group_waves_1 = getenv("RT_GROUP_WAVES") && atoi(getenv("RT_GROUP_WAVES")) == 1;
+    ctx->env_no_tile_order = env_on("RT_NO_TILE_ORDER");
+    ctx->env_no_slices = env_on("RT_NO_SLICES");
+    ctx->env_mesh_in_global = env_on("RT_MESH_IN_GLOBAL");
+    ctx->env_no_probe = env_on("RT_NO_PROBE");
     *out = ctx;
     return RT_OK;
 }
@@ -479,6 +521,7 @@ void rt_destroy(rt_ctx* ctx)
     (void)hipFree(ctx->d_stats);
     (void)hipFree(ctx->d_tile_cost);
     (void)hipFree(ctx->d_tile_order);
+    (void)hipFree(ctx->d_stage);
     delete ctx;
 }
 
@@ -496,8 +539,7 @@ int rt_upload_shapes(rt_ctx* ctx, const rt_shape* shapes, uint32_t n)
     if (!ctx) return RT_ERR_INVALID_ARG;
     RT_REQUIRE(ctx, n == 0 || shapes, "rt_upload_shapes: shapes is NULL");
     try { ctx->shapes.assign(shapes, shapes + n); } catch (...) { return fail(ctx, RT_ERR_OUT_OF_MEMORY, "rt_upload_shapes: host allocation failed"); }
-    ctx->blob_dirty = true;
-    return build_blob(ctx);
+    return scene_changed(ctx);
 }
 
 int rt_upload_triangles(rt_ctx* ctx, const rt_triangle* tris, uint32_t n)
@@ -507,8 +549,7 @@ int rt_upload_triangles(rt_ctx* ctx, const rt_triangle* tris, uint32_t n)
     RT_REQUIRE(ctx, n <= (1u << 26) - 4u, "rt_upload_triangles: more than 2^26 triangles (a leaf's number must fit 24 bits)");
     try { ctx->tris.assign(tris, tris + n); } catch (...) { return fail(ctx, RT_ERR_OUT_OF_MEMORY, "rt_upload_triangles: host allocation failed"); }
     ctx->tri_colors.clear();
-    ctx->blob_dirty = true;
-    return build_blob(ctx);
+    return scene_changed(ctx);
 }
 
 int rt_upload_triangle_colors(rt_ctx* ctx, const float* rgb, uint32_t n)
@@ -518,8 +559,13 @@ int rt_upload_triangle_colors(rt_ctx* ctx, const float* rgb, uint32_t n)
     if (n != 0 && n != ctx->tris.size())
         return fail(ctx, RT_ERR_INVALID_ARG, "rt_upload_triangle_colors: %u colours for %zu uploaded triangles", n, ctx->tris.size());
     try { ctx->tri_colors.assign(rgb, rgb + 3u * (size_t)n); } catch (...) { return fail(ctx, RT_ERR_OUT_OF_MEMORY, "rt_upload_triangle_colors: host allocation failed"); }
-    ctx->blob_dirty = true;
-    return build_blob(ctx);
+    return scene_changed(ctx);
+}
+
+int rt_commit_scene(rt_ctx* ctx)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    return ctx->blob_dirty ? build_blob(ctx) : RT_OK;
 }
 
 int rt_set_camera(rt_ctx* ctx, const float data[RT_CAMERA_FLOATS])
@@ -632,7 +678,10 @@ static int fill_params(rt_ctx* ctx, rtd::TraceParams& P, uint32_t width, uint32_
     // Four waves per workgroup share one staged copy of the scene.  Single-wave workgroups (RT_GROUP_WAVES=1, for
     // measurements) free their slot the moment the wave ends: no faster on the four-sphere scene (1.34 against
     // 1.36 ms), 2.2 times slower on the mesh scene, where the staged scene then limits the waves per CU.
-    P.group_waves = (getenv("RT_GROUP_WAVES") && atoi(getenv("RT_GROUP_WAVES")) == 1) ? 1u : 4u;
+    P.group_waves = ctx->env_group_waves_1 ? 1u : 4u;
+    // tile_plan_kernel counts the entries of its three classes in fields of 21 bits, and a sliced frame has up to
+    // twice as many entries as tiles.
+    RT_REQUIRE(ctx, (uint64_t)P.tiles_x * P.tiles_y < (1u << 20), "render: more than 2^20 tiles of 16x16 pixels");
     return RT_OK;
 }
 
@@ -652,12 +701,57 @@ static int ensure_tiles(rt_ctx* ctx, const rtd::TraceParams& P)
     return RT_OK;
 }
 
-// One launch of the trace kernel: one workgroup per 16x16-pixel tile.
-static int launch_tiles(rt_ctx* ctx, int mode, rtd::TraceParams& P, uint32_t* accum, int32_t* th, uint32_t* tm,
-                        const uint32_t* plan, uint32_t* cost, uint32_t n_workgroups)
+// How many slices a tile's sample range may be cut into.  Slices are added with integer atomics, which only the
+// shader's sums allow (a float sum depends on the order of its terms); each keeps at least 16 samples.
+static uint32_t slices_allowed(const rt_ctx* ctx, uint32_t spp)
 {
-    RT_HIP(ctx, rtd::launch_trace((int)ctx->cfg.semantics, mode, ctx->stream, P, ctx->d_blob, accum, ctx->d_stats, th, tm,
-                                  plan, cost, n_workgroups));
+    if (ctx->cfg.semantics != RT_SEM_GLSL || spp >= (1u << 24) || ctx->env_no_slices) return 1u;
+    return std::min(16u, std::max(1u, spp / 16u));
+}
+
+// Turns the tile costs in `cost` into the plan of a launch of `spp` samples per pixel -> its number of workgroups.
+static int make_plan(rt_ctx* ctx, uint32_t* cost, uint32_t* order, uint32_t n_tiles, uint32_t spp, uint32_t* plan_units)
+{
+    const uint32_t max_slices = slices_allowed(ctx, spp);
+    const uint32_t extra = max_slices > 1u ? n_tiles : 0u;
+    // A tile is cut when it costs more than a quarter of an even share (measured: 0.5 -> 48 ms, 0.35 -> 45,
+    // 0.25 -> 41, 0.125 -> 41 on the 292-triangle mesh scene; no effect on scenes without expensive tiles).
+    const float share = 0.25f;
+    // Uncut tiles above half the cutting threshold are as long as the slices and follow them directly (measured on the
+    // same scene: 41.0 ms without, 39.1-40.3 ms with; putting them before the slices instead: the same).
+    const float early_share = 0.5f;
+    RT_HIP(ctx, rtd::launch_tile_plan(ctx->stream, cost, order, n_tiles, extra, max_slices, share, early_share));
+    *plan_units = n_tiles + extra;
+    return RT_OK;
+}
+
+// A render call of at least this many samples per pixel that has no plan yet traces its first PROBE_SPP samples in
+// the built-in order, makes the plan from what the tiles cost there, and traces the rest by that plan.
+constexpr uint32_t PROBE_MIN_SPP = 64u, PROBE_SPP = 16u;
+
+// Traces samples [P.first_sample, P.first_sample + P.spp) into `accum`: one launch by the plan in `order` (have_plan),
+// or — without a plan — a probe launch, the plan made from it, and the rest; without a plan and with few samples,
+// one launch in the built-in order.  `cost` (n_tiles words, zero on entry) collects what the tiles cost; with
+// plan_after the plan of the next frame is made from it and left in `order` (and `cost` is zero again).
+// *plan_units: in, the workgroups of the plan in `order`; out, those of the plan left there.
+static int trace_frame(rt_ctx* ctx, rtd::TraceParams P, uint32_t* accum, int mode, uint32_t* cost, uint32_t* order,
+                       bool have_plan, bool allow_probe, bool plan_after, uint32_t* plan_units, int32_t* d_timeline)
+{
+    const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    const uint32_t spp_all = P.spp;
+    if (!have_plan && allow_probe && P.spp >= PROBE_MIN_SPP) {
+        rtd::TraceParams probe = P;
+        probe.spp = PROBE_SPP;
+        RT_HIP(ctx, rtd::launch_trace((int)ctx->cfg.semantics, mode, ctx->stream, probe, ctx->d_blob, accum, ctx->d_stats, nullptr, nullptr,
+                                      nullptr, cost, n_tiles));
+        P.first_sample += PROBE_SPP; P.spp -= PROBE_SPP;
+        int rc = make_plan(ctx, cost, order, n_tiles, P.spp, plan_units);
+        if (rc) return rc;
+        have_plan = true;
+    }
+    RT_HIP(ctx, rtd::launch_trace((int)ctx->cfg.semantics, mode, ctx->stream, P, ctx->d_blob, accum, ctx->d_stats, d_timeline, nullptr,
+                                  have_plan ? order : nullptr, cost, have_plan ? *plan_units : n_tiles));
+    if (plan_after) return make_plan(ctx, cost, order, n_tiles, spp_all, plan_units);
     return RT_OK;
 }
 
@@ -667,52 +761,44 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
 {
     if (!ctx) return RT_ERR_INVALID_ARG;
     RT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = RT_OK;
+    if (ctx->blob_dirty) { rc = build_blob(ctx); if (rc) return rc; }
     rtd::TraceParams P;
-    int rc = fill_params(ctx, P, width, height, spp, max_depth, seed, first_sample, grid_n);
+    rc = fill_params(ctx, P, width, height, spp, max_depth, seed, first_sample, grid_n);
     if (rc) return rc;
     rc = ensure_accum(ctx, width, height);
     if (rc) return rc;
     if (stats) RT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * rtd::ST_COUNT, ctx->stream));
-    if (ctx->blob_dirty) { rc = build_blob(ctx); if (rc) return rc; }
     if (spp > 0 && P.owned_rows > 0) {
         rc = ensure_tiles(ctx, P);
         if (rc) return rc;
         const uint32_t n_tiles = P.tiles_x * P.tiles_y;
-        // The plan made from the last frame holds while the tiling stays the same; a new
-        // tiling starts from the built-in order and clean costs.
-        const bool have_plan = ctx->order_tiles_x == P.tiles_x && ctx->order_tiles_y == P.tiles_y && !getenv("RT_NO_TILE_ORDER");
+        // The plan made from the last frame holds while the tiling stays the same; a new tiling starts from clean
+        // costs.  A plan that cuts tiles into slices of the sample range (it then has more entries than tiles) is
+        // dropped for a call of 2^24 samples or more, which the slices' arithmetic (spp * slice) does not hold.
+        const bool have_plan = ctx->order_tiles_x == P.tiles_x && ctx->order_tiles_y == P.tiles_y && !ctx->env_no_tile_order &&
+                               (spp < (1u << 24) || ctx->plan_units == n_tiles);
         if (!have_plan) RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, sizeof(uint32_t) * n_tiles, ctx->stream));
-        const uint32_t n_workgroups = have_plan ? ctx->plan_units : n_tiles;
+        uint32_t plan_units = have_plan ? ctx->plan_units : n_tiles;
         int32_t* d_timeline = nullptr;
         if (timeline_host) {
-            if (timeline_waves < 4u * n_workgroups) return fail(ctx, RT_ERR_INVALID_ARG, "timeline buffer holds %u waves, the launch has %u", timeline_waves, 4u * n_workgroups);
-            RT_HIP(ctx, hipMalloc(&d_timeline, sizeof(int32_t) * 16u * n_workgroups));
-            RT_HIP(ctx, hipMemsetAsync(d_timeline, 0, sizeof(int32_t) * 16u * n_workgroups, ctx->stream));
+            if (timeline_waves < 4u * plan_units) return fail(ctx, RT_ERR_INVALID_ARG, "timeline buffer holds %u waves, the launch has %u", timeline_waves, 4u * plan_units);
+            RT_HIP(ctx, hipMalloc(&d_timeline, sizeof(int32_t) * 16u * plan_units));
+            RT_HIP(ctx, hipMemsetAsync(d_timeline, 0, sizeof(int32_t) * 16u * plan_units, ctx->stream));
         }
-        rc = launch_tiles(ctx, stats ? 1 : 0, P, accum_ptr(ctx), d_timeline, nullptr,
-                          have_plan ? ctx->d_tile_order : nullptr, ctx->d_tile_cost, n_workgroups);
+        const uint32_t launched = plan_units;
+        rc = trace_frame(ctx, P, accum_ptr(ctx), stats ? 1 : 0, ctx->d_tile_cost, ctx->d_tile_order, have_plan,
+                         !timeline_host && !ctx->env_no_probe && !ctx->env_no_tile_order, true, &plan_units, d_timeline);
         if (rc) { if (d_timeline) (void)hipFree(d_timeline); return rc; }
         hipError_t le = hipSuccess;
-        if (le == hipSuccess && d_timeline) {
-            le = hipMemcpyAsync(timeline_host, d_timeline, sizeof(int32_t) * 16u * n_workgroups, hipMemcpyDeviceToHost, ctx->stream);
+        if (d_timeline) {
+            le = hipMemcpyAsync(timeline_host, d_timeline, sizeof(int32_t) * 16u * launched, hipMemcpyDeviceToHost, ctx->stream);
             if (le == hipSuccess) le = hipStreamSynchronize(ctx->stream);
+            (void)hipFree(d_timeline);
         }
-        if (d_timeline) (void)hipFree(d_timeline);
         RT_HIP(ctx, le);
-        // Slices of a tile's sample range are added with integer atomics, which only the shader's
-        // sums allow (a float sum depends on the order of its terms); each keeps at least 16 samples.
-        uint32_t max_slices = 1u;
-        if (ctx->cfg.semantics == RT_SEM_GLSL && spp < (1u << 24) && !getenv("RT_NO_SLICES")) max_slices = std::min(16u, std::max(1u, spp / 16u));
-        const uint32_t extra = max_slices > 1u ? n_tiles : 0u;
-        // A tile is cut when it costs more than a quarter of an even share (measured: 0.5 -> 48 ms, 0.35 -> 45,
-        // 0.25 -> 41, 0.125 -> 41 on the 292-triangle mesh scene; no effect on scenes without expensive tiles).
-        const float share = 0.25f;
-        // Uncut tiles above half the cutting threshold are as long as the slices and follow them directly (measured on the
-        // same scene: 41.0 ms without, 39.1-40.3 ms with; putting them before the slices instead: the same).
-        const float early_share = 0.5f;
-        RT_HIP(ctx, rtd::launch_tile_plan(ctx->stream, ctx->d_tile_cost, ctx->d_tile_order, n_tiles, extra, max_slices, share, early_share));
         ctx->order_tiles_x = P.tiles_x; ctx->order_tiles_y = P.tiles_y;
-        ctx->plan_units = n_tiles + extra;
+        ctx->plan_units = plan_units;
     }
     ctx->accum_samples += spp;
     if (stats) {
@@ -795,6 +881,17 @@ int rt_resolve_device(rt_ctx* ctx, float* rgba_device, int gamma_sqrt, int flip_
     return RT_OK;
 }
 
+// Device staging of at least `bytes` for the entry points that hand results to host memory; kept between calls.
+static int ensure_stage(rt_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->stage_cap) return RT_OK;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_stage) { RT_HIP(ctx, hipFree(ctx->d_stage)); ctx->d_stage = nullptr; ctx->stage_cap = 0; }
+    RT_HIP(ctx, hipMalloc(&ctx->d_stage, bytes));
+    ctx->stage_cap = bytes;
+    return RT_OK;
+}
+
 int rt_resolve(rt_ctx* ctx, float* rgba_host, int gamma_sqrt, int flip_rows)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;
@@ -802,15 +899,15 @@ int rt_resolve(rt_ctx* ctx, float* rgba_host, int gamma_sqrt, int flip_rows)
     if (!accum_ptr(ctx) || ctx->accum_samples == 0) return fail(ctx, RT_ERR_STATE, "resolve: nothing has been rendered");
     RT_HIP(ctx, hipSetDevice(ctx->device));
     const size_t bytes = (size_t)ctx->width * ctx->height * 16u;
-    float* tmp = nullptr;
-    RT_HIP(ctx, hipMalloc(&tmp, bytes));
-    int rc = rt_resolve_device(ctx, tmp, gamma_sqrt, flip_rows);
+    int rc = ensure_stage(ctx, bytes);
+    if (rc) return rc;
+    float* const tmp = static_cast<float*>(ctx->d_stage);
+    rc = rt_resolve_device(ctx, tmp, gamma_sqrt, flip_rows);
     if (rc == RT_OK) {
         hipError_t e = hipMemcpyAsync(rgba_host, tmp, bytes, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "resolve copy-back failed: %s", hipGetErrorString(e));
     }
-    (void)hipFree(tmp);
     return rc;
 }
 
@@ -852,30 +949,28 @@ int rt_trace_debug(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t max_de
     if (!ctx) return RT_ERR_INVALID_ARG;
     RT_REQUIRE(ctx, hit_index_host && material_id_host, "rt_trace_debug: output is NULL");
     RT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = RT_OK;
+    if (ctx->blob_dirty) { rc = build_blob(ctx); if (rc) return rc; }
     rtd::TraceParams P;
     // The trace ignores sharding: it follows every pixel.
     const uint32_t si = ctx->shard_index, sc = ctx->shard_count;
     ctx->shard_index = 0; ctx->shard_count = 1;
-    int rc = fill_params(ctx, P, width, height, 1, max_depth, seed, sample, grid_n ? grid_n : (ctx->cfg.sample_mode ? 0u : 1u));
+    rc = fill_params(ctx, P, width, height, 1, max_depth, seed, sample, grid_n ? grid_n : (ctx->cfg.sample_mode ? 0u : 1u));
     ctx->shard_index = si; ctx->shard_count = sc;
     if (rc) return rc;
     P.trace_sample = sample;
     const size_t n = (size_t)width * height * max_depth;
-    int32_t* d_hit = nullptr; uint32_t* d_mat = nullptr;
-    RT_HIP(ctx, hipMalloc(&d_hit, n * sizeof(int32_t)));
-    hipError_t e = hipMalloc(&d_mat, n * sizeof(uint32_t));
-    if (e != hipSuccess) { (void)hipFree(d_hit); return fail(ctx, RT_ERR_OUT_OF_MEMORY, "hipMalloc(trace): %s", hipGetErrorString(e)); }
-    e = rtd::launch_trace_fill(ctx->stream, d_hit, d_mat, n);
+    rc = ensure_stage(ctx, n * (sizeof(int32_t) + sizeof(uint32_t)));
+    if (rc) return rc;
+    int32_t* const d_hit = static_cast<int32_t*>(ctx->d_stage);
+    uint32_t* const d_mat = reinterpret_cast<uint32_t*>(d_hit + n);
+    RT_HIP(ctx, rtd::launch_trace_fill(ctx->stream, d_hit, d_mat, n));
     // accum is not touched by a TRACE launch; pass any valid pointer.
-    if (e == hipSuccess) {
-        rc = launch_tiles(ctx, 2, P, reinterpret_cast<uint32_t*>(d_hit), d_hit, d_mat, nullptr, nullptr, P.tiles_x * P.tiles_y);
-        if (rc) { (void)hipFree(d_hit); (void)hipFree(d_mat); return rc; }
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(hit_index_host, d_hit, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(material_id_host, d_mat, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_hit); (void)hipFree(d_mat);
-    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, "rt_trace_debug failed: %s", hipGetErrorString(e));
+    RT_HIP(ctx, rtd::launch_trace((int)ctx->cfg.semantics, 2, ctx->stream, P, ctx->d_blob, reinterpret_cast<uint32_t*>(d_hit), ctx->d_stats,
+                                  d_hit, d_mat, nullptr, nullptr, P.tiles_x * P.tiles_y));
+    RT_HIP(ctx, hipMemcpyAsync(hit_index_host, d_hit, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(material_id_host, d_mat, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
 

@@ -195,8 +195,17 @@ int rt_mesh_load(rt_mesh** out, const char* path)
     if (fscanf(f, "%4s", tag) != 1 || fscanf(f, "%u %u %u", &nv, &np, &ne) != 3) { fclose(f); return RT_ERR_IO; }
     const bool coff = strcmp(tag, "COFF") == 0;
     if (!coff && strcmp(tag, "OFF") != 0) { fclose(f); return RT_ERR_IO; }   // :198-201
+    // Every vertex and every face takes at least six characters of the file ("0 0 0\n", "3 0 0 0\n"): a header that
+    // promises more than the file can hold is rejected before anything is reserved for it.
+    {
+        const long here = ftell(f);
+        long size = -1;
+        if (here >= 0 && fseek(f, 0, SEEK_END) == 0) { size = ftell(f); (void)fseek(f, here, SEEK_SET); }
+        if (size < 0 || ((uint64_t)nv + (uint64_t)np) * 6u > (uint64_t)size) { fclose(f); return RT_ERR_IO; }
+    }
     rt_mesh* mesh = new (std::nothrow) rt_mesh();
     if (!mesh) { fclose(f); return RT_ERR_OUT_OF_MEMORY; }
+    try {
     mesh->vertices.reserve(nv); mesh->indices.reserve((size_t)np * 3);
     for (unsigned i = 0; i < nv; ++i) {
         rt_mesh::Vertex v{};
@@ -217,6 +226,7 @@ int rt_mesh_load(rt_mesh** out, const char* path)
             fscanf(f, "%u %u %u", &a, &b, &c) != 3 || a >= nv || b >= nv || c >= nv) { delete mesh; fclose(f); return RT_ERR_IO; }
         mesh->indices.push_back(a); mesh->indices.push_back(b); mesh->indices.push_back(c);
     }
+    } catch (...) { delete mesh; fclose(f); return RT_ERR_OUT_OF_MEMORY; }
     fclose(f);
     *out = mesh;
     return RT_OK;
@@ -322,14 +332,21 @@ uint32_t rt_mesh_add_vertex(rt_mesh* mesh, const float position[4], const float 
     rt_mesh::Vertex v{};
     memcpy(v.position, position, 16);
     if (color) memcpy(v.color, color, 16);
-    mesh->vertices.push_back(v);
+    try { mesh->vertices.push_back(v); } catch (...) { return 0xffffffffu; }
     return (uint32_t)mesh->vertices.size() - 1u;
 }
 
 uint32_t rt_mesh_add_face(rt_mesh* mesh, uint32_t idx0, uint32_t idx1, uint32_t idx2)      // SimpleMesh.h:99-104
 {
     if (!mesh) return 0xffffffffu;
-    mesh->indices.push_back(idx0); mesh->indices.push_back(idx1); mesh->indices.push_back(idx2);
+    // rt_mesh_to_triangles and rt_mesh_triangle_colors index the vertices with these: a face may only name vertices
+    // that exist (the same rule rt_mesh_load applies to a file's faces).
+    const size_t nv = mesh->vertices.size();
+    if (idx0 >= nv || idx1 >= nv || idx2 >= nv) return 0xffffffffu;
+    try {
+        mesh->indices.reserve(mesh->indices.size() + 3u);
+        mesh->indices.push_back(idx0); mesh->indices.push_back(idx1); mesh->indices.push_back(idx2);
+    } catch (...) { return 0xffffffffu; }
     return (uint32_t)(mesh->indices.size() / 3) - 1u;
 }
 
@@ -370,6 +387,7 @@ int rt_mesh_join(rt_mesh** out, const rt_mesh* mesh1, const rt_mesh* mesh2, cons
     rt_mesh* joined = new (std::nothrow) rt_mesh();
     if (!joined) return RT_ERR_OUT_OF_MEMORY;
     const uint32_t n1 = (uint32_t)mesh1->vertices.size();
+    try {
     joined->vertices.reserve(n1 + mesh2->vertices.size());
     for (const auto& v1 : mesh1->vertices) {                     // :270-276
         rt_mesh::Vertex v{};
@@ -386,6 +404,7 @@ int rt_mesh_join(rt_mesh** out, const rt_mesh* mesh1, const rt_mesh* mesh2, cons
     for (const auto& v2 : mesh2->vertices) joined->vertices.push_back(v2);                  // :277
     joined->indices = mesh1->indices;                                                       // :280
     for (uint32_t idx : mesh2->indices) joined->indices.push_back(idx + n1);                // :281-285
+    } catch (...) { delete joined; return RT_ERR_OUT_OF_MEMORY; }
     *out = joined;
     return RT_OK;
 }
@@ -406,6 +425,7 @@ int rt_mesh_sphere(rt_mesh** out, const float center[3], float scale, const floa
                                     { 0, 1, 6 }, { 6, 1, 10 }, { 9, 0, 11 }, { 9, 11, 2 }, { 9, 2, 5 }, { 7, 2, 11 } };   // :300-301
     const float default_color[4] = { 0, 0, 1, 1 };               // :293
     const float* col = color ? color : default_color;
+    try {
     for (int i = 0; i < 12; ++i) {                               // :304-309
         rt_mesh::Vertex v{};
         for (int k = 0; k < 3; ++k) v.position[k] = center[k] + scale * (float)verts[i][k];
@@ -414,6 +434,7 @@ int rt_mesh_sphere(rt_mesh** out, const float center[3], float scale, const floa
         mesh->vertices.push_back(v);
     }
     for (int i = 0; i < 20; ++i) for (int k = 0; k < 3; ++k) mesh->indices.push_back(faces[i][k]);   // :312-314
+    } catch (...) { delete mesh; return RT_ERR_OUT_OF_MEMORY; }
     *out = mesh;
     return RT_OK;
 }

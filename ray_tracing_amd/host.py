@@ -308,6 +308,7 @@ class RayTracingComputeShader:
         if self.triangle_colors is not None and len(self.triangle_colors):
             c = np.ascontiguousarray(self.triangle_colors, dtype=np.float32).reshape(-1, 3)
             self._check(lib.rt_upload_triangle_colors(self._ctx, c.ctypes.data, len(c)))
+        self._check(lib.rt_commit_scene(self._ctx))      # one build of the device copy for all three uploads
 
     def compute(self, x, y, z=1, spp=None, first_sample=None):   # :39-42
         """One dispatch over x * y pixels: samples_per_frame new samples per pixel."""
