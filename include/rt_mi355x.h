@@ -237,6 +237,23 @@ int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp,
               uint32_t max_depth, uint64_t seed, uint32_t first_sample,
               uint32_t grid_n);
 
+/* rt_render for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid it).  No counterpart in the reference.  It adds the same
+ * samples to `accum_device` (caller-owned, width*height*4 32-bit words, 16-byte aligned, on the
+ * context's device) as rt_render adds to its accumulator — bit for bit — and calls no hipMalloc /
+ * hipFree: the per-tile costs and the launch plan that rt_render keeps in memory of its own live
+ * in a static device array of the library instead (768 KiB, held by every GPU the library has been
+ * used on until the process ends).  Limits: at most RT_NOALLOC_MAX_TILES tiles of 16x16 pixels
+ * (more: RT_ERR_INVALID_ARG); the scene must have been built (rt_commit_scene or an earlier
+ * render; else RT_ERR_STATE).  All calls on one GPU share the one array: calls that overlap there
+ * (two streams, two contexts, two threads) race on it and may trace tiles twice or not at all.
+ * The context's own accumulator, sample count and plan are left alone.  Asynchronous on the
+ * context's stream. */
+#define RT_NOALLOC_MAX_TILES 65536u
+int rt_render_noalloc(rt_ctx* ctx, void* accum_device, uint32_t width, uint32_t height,
+                      uint32_t spp, uint32_t max_depth, uint64_t seed, uint32_t first_sample,
+                      uint32_t grid_n);
+
 /* The same render, and also fills `out` with the work counters (synchronises
  * the stream).  The image produced is bit-identical to rt_render's. */
 int rt_render_stats(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp,

@@ -47,6 +47,8 @@ class Stats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+NOALLOC_MAX_TILES = 65536                # RT_NOALLOC_MAX_TILES
+
 _vp, _u32, _u64, _i32, _int = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_int
 _fp = C.POINTER(C.c_float)
 
@@ -64,6 +66,7 @@ SIGNATURES = {
     "rt_bind_accum": (_int, [_vp, _vp, _u32, _u32]),
     "rt_commit_scene": (_int, [_vp]),
     "rt_render": (_int, [_vp, _u32, _u32, _u32, _u32, _u64, _u32, _u32]),
+    "rt_render_noalloc": (_int, [_vp, _vp, _u32, _u32, _u32, _u32, _u64, _u32, _u32]),
     "rt_render_stats": (_int, [_vp, _u32, _u32, _u32, _u32, _u64, _u32, _u32, C.POINTER(Stats)]),
     "rt_render_timeline": (_int, [_vp, _u32, _u32, _u32, _u32, _u64, _u32, _u32, C.POINTER(Stats), _vp, _u32]),
     "rt_accum_samples": (_int, [_vp, C.POINTER(_u32)]),

@@ -31,6 +31,7 @@ hipError_t launch_resolve(int sem, hipStream_t stream, const uint32_t* accum, fl
                           uint32_t samples, int gamma_sqrt, int flip_rows);
 hipError_t launch_convert(int sem, hipStream_t stream, uint32_t* accum, float* image, uint32_t w, uint32_t h,
                           uint32_t samples, uint32_t n_samples);
+hipError_t scratch_for_device(int device, uint32_t** out);
 }  // namespace rtd
 
 static_assert(sizeof(rt_material) == 32, "Material layout (shape.h:5-12)");
@@ -78,6 +79,8 @@ struct rt_ctx {
 
     int compute_units = 0;
 
+    // This device's copy of the library's static scratch (rt_render_noalloc), looked up once in rt_create.
+    uint32_t* d_scratch = nullptr;
     // Staging for entry points that return data to host memory (rt_resolve, rt_trace_debug): grown on demand, kept.
     void* d_stage = nullptr;             size_t stage_cap = 0;
     // Switches for measurements, read from the environment once, when the context is created.
@@ -500,6 +503,9 @@ int rt_create(rt_ctx** out, const rt_config* cfg)
     e = hipGetDeviceProperties(&prop, c.device);
     if (e != hipSuccess) { (void)hipFree(ctx->d_stats); delete ctx; return fail(nullptr, RT_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); }
     ctx->compute_units = prop.multiProcessorCount;
+    // This device's address of the library's static scratch (the device is current here); rt_render_noalloc uses it.
+    e = rtd::scratch_for_device(c.device, &ctx->d_scratch);
+    if (e != hipSuccess) { (void)hipFree(ctx->d_stats); delete ctx; return fail(nullptr, RT_ERR_HIP, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e)); }
     auto env_on = [](const char* name) { const char* v = getenv(name); return v && *v && strcmp(v, "0") != 0; };
     ctx->env_group_waves_1 = getenv("RT_GROUP_WAVES") && atoi(getenv("RT_GROUP_WAVES")) == 1;
     ctx->env_no_tile_order = env_on("RT_NO_TILE_ORDER");
@@ -823,6 +829,32 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         stats->box_bound_tests_done = h[rtd::ST_BOX_BOUNDS];
     }
     return RT_OK;
+}
+
+int rt_render_noalloc(rt_ctx* ctx, void* accum_device, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth,
+                      uint64_t seed, uint32_t first_sample, uint32_t grid_n)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    RT_REQUIRE(ctx, accum_device, "rt_render_noalloc: accumulator is NULL");
+    RT_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(accum_device) & 15u) == 0, "rt_render_noalloc: accumulator must be 16-byte aligned");
+    if (ctx->blob_dirty) return fail(ctx, RT_ERR_STATE, "rt_render_noalloc: the scene has changed since it was last built; call rt_commit_scene first");
+    if (!ctx->d_scratch) return fail(ctx, RT_ERR_STATE, "rt_render_noalloc: no scratch on this device");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    rtd::TraceParams P;
+    int rc = fill_params(ctx, P, width, height, spp, max_depth, seed, first_sample, grid_n);
+    if (rc) return rc;
+    const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    if (n_tiles > RT_NOALLOC_MAX_TILES)
+        return fail(ctx, RT_ERR_INVALID_ARG, "rt_render_noalloc: %u tiles of 16x16 pixels, the static scratch holds %u (use rt_render)",
+                    n_tiles, (unsigned)RT_NOALLOC_MAX_TILES);
+    if (spp == 0 || P.owned_rows == 0) return RT_OK;
+    // The scratch keeps what the last call on this device left: the costs start at zero, the plan is written whole
+    // before it is read.
+    uint32_t* const cost = ctx->d_scratch;
+    uint32_t* const order = ctx->d_scratch + RT_NOALLOC_MAX_TILES;
+    RT_HIP(ctx, hipMemsetAsync(cost, 0, sizeof(uint32_t) * n_tiles, ctx->stream));
+    uint32_t plan_units = n_tiles;
+    return trace_frame(ctx, P, static_cast<uint32_t*>(accum_device), 0, cost, order, false, true, false, &plan_units, nullptr);
 }
 
 int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth,

@@ -33,6 +33,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <mutex>
+#include "../../include/rt_mi355x.h"
 #include "rt_device.h"
 
 namespace rtd {
@@ -1163,6 +1165,34 @@ __global__ void convert_kernel(uint32_t* __restrict__ accum, float* __restrict__
     }
     *ip = cur;
     *ap = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// ------------------------------------------------------------ static scratch
+// Per-tile costs (RT_NOALLOC_MAX_TILES words) and the launch plan (twice as many) of rt_render_noalloc, the render
+// call that allocates nothing.  In host code the array's name is only a handle for hipGetSymbolAddress: each GPU
+// holds its own copy at its own address, looked up once per device (with that device current) and kept; kernels,
+// memsets and copies get that pointer, never the name.
+constexpr uint32_t SCRATCH_WORDS = 3u * RT_NOALLOC_MAX_TILES;
+static __device__ __align__(256) uint32_t scratch[SCRATCH_WORDS];
+
+constexpr int SCRATCH_MAX_DEVICES = 64;
+static uint32_t* g_scratch_ptr[SCRATCH_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+// -> this device's address of `scratch`.  `device` must be the current device.
+hipError_t scratch_for_device(int device, uint32_t** out)
+{
+    *out = nullptr;
+    if (device < 0 || device >= SCRATCH_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = static_cast<uint32_t*>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
 }
 
 // ------------------------------------------------------------ host launchers

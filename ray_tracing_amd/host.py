@@ -346,6 +346,11 @@ class RayTracingComputeShader:
         self._check(lib.rt_render(self._ctx, width, height, spp, max_depth, seed, first_sample, grid_n))
         return None
 
+    def renderNoAlloc(self, accum_device_ptr, width, height, spp, max_depth, seed, first_sample=0, grid_n=0):
+        """rt_render for callers that cannot allocate: adds into caller-owned device memory, uses the library's static scratch."""
+        self._check(lib.rt_render_noalloc(self._ctx, C.c_void_p(accum_device_ptr), width, height, spp, max_depth, seed,
+                                          first_sample, grid_n))
+
     def resetAccum(self):
         self._check(lib.rt_reset_accum(self._ctx))
         self.frame = 0
