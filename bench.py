@@ -116,6 +116,16 @@ def cpu_baseline(cfg, target_seconds=12.0, gpu_render=None):
         out["image_vs_cpu"] = {"frame": f"{cfg.width}x{cfg.height}, {spp} spp", "differing_words": differing,
                                "psnr_db": None if mse == 0.0 else round(10.0 * float(np.log10(max(a.max(), 1e-30) ** 2 / mse)), 2),
                                "note": "psnr_db null = the two frames are bit-identical (infinite PSNR)"}
+        # The same frame once more in the reference's literal arithmetic (no FMA, IEEE divide, v / sqrt(v.v), libm
+        # sin / cos): the GPU's frame against the source text rather than against the recipes it shares with the oracle.
+        p.arith = orc.ARITH_LITERAL
+        lit, _ = orc.render(cfg.shapes, cfg.triangles, cfg.camera, p)
+        c = orc.resolve(lit, spp, cfg.semantics, gamma_sqrt=(cfg.semantics == 0))[..., :3].astype(np.float64)
+        mse = float(((c - b) ** 2).mean())
+        out["image_vs_cpu"]["literal_arithmetic"] = {
+            "psnr_db": None if mse == 0.0 else round(10.0 * float(np.log10(max(c.max(), 1e-30) ** 2 / mse)), 2),
+            "max_abs": round(float(np.abs(c - b).max()), 6),
+            "pixels_differing_percent": round(100.0 * float((np.abs(c - b).max(axis=-1) > 0).mean()), 4)}
     return out
 
 

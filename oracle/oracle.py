@@ -18,6 +18,7 @@ COLOR_AS_WRITTEN, COLOR_FORWARD = 0, 1
 UNIT_DIRECT, UNIT_GAUSS = 0, 1
 RNG_HASH, RNG_GLSL = 0, 1
 FLAG_METAL_UNNORMALIZED, FLAG_BOX_SIDES = 1, 2
+ARITH_RECIPE, ARITH_LITERAL = 0, 1
 
 
 class Params(C.Structure):
@@ -26,7 +27,7 @@ class Params(C.Structure):
                 ("semantics", C.c_uint32), ("sample_mode", C.c_uint32), ("flags", C.c_uint32),
                 ("triangle_albedo", C.c_float * 3), ("color_order", C.c_uint32), ("unit_sampler", C.c_uint32),
                 ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("band_rows", C.c_uint32),
-                ("threads", C.c_int32), ("rng", C.c_uint32), ("triangle_colors", C.c_void_p)]
+                ("threads", C.c_int32), ("rng", C.c_uint32), ("triangle_colors", C.c_void_p), ("arith", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -54,6 +55,7 @@ def _load():
     lib.orc_resolve.argtypes = [vp, u32, u32, u32, u32, C.c_int, C.c_int, vp]
     lib.orc_convert.restype = None
     lib.orc_convert.argtypes = [vp, vp, u32, u32, u32, u32, u32]
+    lib.orc_set_arith.restype = None; lib.orc_set_arith.argtypes = [C.c_int]
     lib.orc_hash32.restype = u32; lib.orc_hash32.argtypes = [u32]
     lib.orc_path_key.restype = u32; lib.orc_path_key.argtypes = [u64, u32, u32]
     lib.orc_draw.restype = C.c_float; lib.orc_draw.argtypes = [u32, u32]
@@ -92,10 +94,10 @@ def _fp(a):
 
 def params(width, height, spp, max_depth, seed=1, semantics=SEM_CPU, sample_mode=SAMPLE_JITTER, flags=0,
            first_sample=0, grid_n=0, triangle_albedo=(1.0, 0.0, 0.0), color_order=COLOR_FORWARD,
-           unit_sampler=UNIT_DIRECT, shard=(0, 1, 16), threads=0, rng=RNG_HASH, triangle_colors=None):
+           unit_sampler=UNIT_DIRECT, shard=(0, 1, 16), threads=0, rng=RNG_HASH, triangle_colors=None, arith=ARITH_RECIPE):
     """triangle_colors: None, or float32 [n_triangles, 3] (kept alive by the returned object)."""
     p = Params(width, height, spp, first_sample, max_depth, grid_n, seed, semantics, sample_mode, flags,
-               (C.c_float * 3)(*triangle_albedo), color_order, unit_sampler, shard[0], shard[1], shard[2], threads, rng, None)
+               (C.c_float * 3)(*triangle_albedo), color_order, unit_sampler, shard[0], shard[1], shard[2], threads, rng, None, arith)
     if triangle_colors is not None and len(triangle_colors):
         p._colors = np.ascontiguousarray(triangle_colors, dtype=np.float32).reshape(-1, 3)
         p.triangle_colors = p._colors.ctypes.data
@@ -138,6 +140,18 @@ def resolve(accum, samples, semantics, gamma_sqrt=False, flip_rows=True):
 def convert(accum, image, samples_in_accum, semantics, n_samples):
     h, w, _ = accum.shape
     lib.orc_convert(accum.ctypes.data, image.ctypes.data, w, h, samples_in_accum, semantics, n_samples)
+
+
+class arithmetic:
+    """with arithmetic(ARITH_LITERAL): ... — the leaf routines below evaluate in that arithmetic on this thread."""
+    def __init__(self, arith):
+        self.arith = arith
+
+    def __enter__(self):
+        lib.orc_set_arith(self.arith)
+
+    def __exit__(self, *exc):
+        lib.orc_set_arith(ARITH_RECIPE)
 
 
 def sincos2pi(u):

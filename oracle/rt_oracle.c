@@ -13,7 +13,7 @@
  * the ORC_UNIT_GAUSS sampler, which uses logf/cosf/sinf, exists only for a
  * statistical cross-check.
  *
- * Arithmetic conventions used throughout:
+ * Arithmetic conventions used throughout (ORC_ARITH_RECIPE; ORC_ARITH_LITERAL, further down, drops them):
  *   dot(a,b)      = fmaf(a.z,b.z, fmaf(a.y,b.y, a.x*b.x))
  *   madd(t,d,o)   = fmaf(t,d,o) per component               (o + t*d)
  *   normalize(v)  = v * rsqrt_nr(dot(v,v))      (rsqrt_nr: fixed Newton recipe, below)
@@ -32,12 +32,25 @@
 
 typedef struct { float x, y, z; } v3;
 
+/* Two arithmetics.  ORC_ARITH_RECIPE (default) is the one the HIP kernels repeat bit for bit: explicit fused
+ * multiply-adds, a * rcp_nr(b) for the shader's divisions, v * rsqrt_nr(v.v) for normalize, a polynomial for
+ * sin/cos.  ORC_ARITH_LITERAL evaluates the reference's source text the way a plain C++ / GLSL compiler without
+ * contraction does: every product and sum rounded on its own (no FMA), IEEE a / b
+ * (RayTracing.glsl:145,161,181), v / sqrt(v.v) for every normalize (scene.h:15,131; glsl:73,75,83,135,162,297),
+ * libm sinf / cosf (glsl:48,69-70), and Sphere::hit's rec.t = -b - sqrt(discriminant) in double (HitRecord::t
+ * is a double and the unqualified sqrt of scene.h:123 is ::sqrt(double)).  It exists to measure how far the
+ * recipes are from the text; nothing is compared bit for bit with it.  The flag belongs to the calling thread. */
+static __thread int t_lit __attribute__((tls_model("initial-exec"))) = 0;
+void orc_set_arith(int arith) { t_lit = arith == ORC_ARITH_LITERAL; }
+/* a*b + c: fused in the recipe arithmetic, two roundings in the literal one */
+static inline float lfma(float a, float b, float c) { return t_lit ? a * b + c : fmaf(a, b, c); }
+
 static inline v3 V(float x, float y, float z) { v3 r = { x, y, z }; return r; }
 static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline v3 vmul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
 static inline v3 vscale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
-static inline float dot(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
-static inline v3 madd(float t, v3 d, v3 o) { return V(fmaf(t, d.x, o.x), fmaf(t, d.y, o.y), fmaf(t, d.z, o.z)); }
+static inline float dot(v3 a, v3 b) { return lfma(a.z, b.z, lfma(a.y, b.y, a.x * b.x)); }
+static inline v3 madd(float t, v3 d, v3 o) { return V(lfma(t, d.x, o.x), lfma(t, d.y, o.y), lfma(t, d.z, o.z)); }
 /* 1/sqrt(q) by a fixed recipe: bit-trick first guess and three Newton steps
  * y <- y * (1.5 - (0.5 q y) y).  Relative error <= 1.3e-7 (about one ulp) for
  * normal q > 0; q = 0 gives a finite value (so normalize(0) = 0), negative q
@@ -59,7 +72,11 @@ static inline float rsqrt_nr(float q)
     }
     return y;
 }
-static inline v3 normalize(v3 v) { return vscale(v, rsqrt_nr(dot(v, v))); }
+static inline v3 normalize(v3 v)
+{
+    if (t_lit) { float len = sqrtf(dot(v, v)); return V(v.x / len, v.y / len, v.z / len); }     /* Eigen normalized(), GLSL normalize() */
+    return vscale(v, rsqrt_nr(dot(v, v)));
+}
 /* 1/x by a fixed recipe: first guess by subtracting the bit pattern from a
  * constant, then three Newton steps y <- y * (2 - x y), each an IEEE
  * operation; relative error <= 2e-7 for normal x of either sign, x = 0 gives
@@ -77,10 +94,10 @@ static inline float rcp_nr(float x)
     }
     return y;
 }
-static inline float div_nr(float a, float b) { return a * rcp_nr(b); }
+static inline float div_nr(float a, float b) { return t_lit ? a / b : a * rcp_nr(b); }
 static inline v3 cross(v3 a, v3 b)
 {
-    return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+    return V(lfma(a.y, b.z, -(a.z * b.y)), lfma(a.z, b.x, -(a.x * b.z)), lfma(a.x, b.y, -(a.y * b.x)));
 }
 /* GLSL sign(): -1, 0 or 1 (NaN -> 0). */
 static inline float fsign(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
@@ -132,7 +149,8 @@ float orc_draw(uint32_t key, uint32_t index)
 float orc_glsl_random(float seed[3])
 {
     seed[0] = seed[0] + 1.78f; seed[1] = seed[1] + 3.1f; seed[2] = seed[2] + 50.78f;      /* :47 */
-    float x = fmaf(seed[2], 51.112f, fmaf(seed[1], 78.233f, seed[0] * 12.9898f));          /* dot  :48 */
+    float x = lfma(seed[2], 51.112f, lfma(seed[1], 78.233f, seed[0] * 12.9898f));          /* dot  :48 */
+    if (t_lit) { float v = sinf(x) * 43758.5453123f; return v - floorf(v); }               /* :48 with libm's sine */
     float t = x * 0x1.45f306p-3f;                                                          /* x / (2 pi) */
     float u = t - floorf(t);
     float c, sn;
@@ -180,6 +198,11 @@ void orc_glsl_seed(uint64_t seed, uint32_t width, uint32_t height, uint32_t gx, 
  * part of utils.h:45. */
 void orc_sincos2pi(float u, float* c_out, float* s_out)
 {
+    if (t_lit) {                                           /* angle = random() * 2 * pi; cos(angle), sin(angle)   glsl:66,69-70 */
+        float angle = (u * 2.0f) * 3.14159265358979323846f;
+        *c_out = cosf(angle); *s_out = sinf(angle);
+        return;
+    }
     float x = fmaf(u, 0x1.921fb6p+1f, -0x1.921fb6p+0f);   /* pi*u - pi/2 */
     float x2 = x * x;
     float ps = -0x1.ae6456p-26f;
@@ -205,8 +228,8 @@ void orc_sincos2pi(float u, float* c_out, float* s_out)
  * z uniform in (-1,1], azimuth uniform. */
 void orc_unit_vector(float u1, float u2, float out[3])
 {
-    float z = fmaf(-2.0f, u1, 1.0f);
-    float r = sqrtf(fmaf(-z, z, 1.0f));
+    float z = lfma(-2.0f, u1, 1.0f);
+    float r = sqrtf(lfma(-z, z, 1.0f));
     float c, s;
     orc_sincos2pi(u2, &c, &s);
     out[0] = r * c; out[1] = r * s; out[2] = z;
@@ -234,17 +257,17 @@ void orc_hemisphere_glsl(const float nn[3], float u1, float u2, float out[3])
     float c, s;
     orc_sincos2pi(u1, &c, &s);                         /* angle = random()*2*pi        :66 */
     float r = u2;                                      /* r = random()                 :67 */
-    float dist = sqrtf(fmaf(-r, r, 1.0f));             /* sqrt(1 - r*r)                :68 */
+    float dist = sqrtf(lfma(-r, r, 1.0f));             /* sqrt(1 - r*r)                :68 */
     float x = c * dist, y = s * dist;                  /*                              :69-70 */
     v3 b1 = V(-n.y, n.x, 0.0f);                        /*                              :71 */
-    float len_xy = sqrtf(fmaf(b1.y, b1.y, b1.x * b1.x));
+    float len_xy = sqrtf(lfma(b1.y, b1.y, b1.x * b1.x));
     if (len_xy < 0.01f) b1 = normalize(V(0.0f, -n.z, n.y));   /*                      :72-73 */
     else b1 = normalize(b1);                           /*                              :75 */
     v3 b2 = cross(n, b1);                              /*                              :77 */
     /* b1*x + b2*y + normal*r                                                          :78 */
-    out[0] = fmaf(n.x, r, fmaf(b2.x, y, b1.x * x));
-    out[1] = fmaf(n.y, r, fmaf(b2.y, y, b1.y * x));
-    out[2] = fmaf(n.z, r, fmaf(b2.z, y, b1.z * x));
+    out[0] = lfma(n.x, r, lfma(b2.x, y, b1.x * x));
+    out[1] = lfma(n.y, r, lfma(b2.y, y, b1.y * x));
+    out[2] = lfma(n.z, r, lfma(b2.z, y, b1.z * x));
 }
 
 /* ------------------------------------------------------------ intersection */
@@ -252,16 +275,27 @@ void orc_hemisphere_glsl(const float nn[3], float u1, float u2, float out[3])
 /* Sphere::hit, scene.h:115-128 == hitSphere, RayTracing.glsl:118-132.
  * Near root only; needs a unit direction.  Returns +inf when there is no
  * real root. */
-float orc_hit_sphere(const float cc[3], float radius, const float oo[3], const float dd[3])
+static double hit_sphere_t(const float cc[3], float radius, const float oo[3], const float dd[3], int t_in_double)
 {
     v3 oc = vsub(V(oo[0], oo[1], oo[2]), V(cc[0], cc[1], cc[2]));   /* scene.h:116 */
     v3 d = V(dd[0], dd[1], dd[2]);
     float b = dot(oc, d);                                            /* :117 */
     float r2 = radius * radius;
-    float c = fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, fmaf(oc.x, oc.x, -r2)));   /* :118 */
-    float disc = fmaf(b, b, -c);                                     /* :119 */
+    float c, disc;
+    if (t_lit) {
+        c = dot(oc, oc) - r2;                                        /* :118 */
+        disc = b * b - c;                                            /* :119 */
+    } else {
+        c = fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, fmaf(oc.x, oc.x, -r2)));
+        disc = fmaf(b, b, -c);
+    }
     if (disc < 0.0f) return INFINITY;                                /* :120 */
-    return -b - sqrtf(disc);                                         /* :123 */
+    if (t_lit && t_in_double) return -(double)b - sqrt((double)disc);   /* :123: rec.t is a double, sqrt is ::sqrt(double) */
+    return -b - sqrtf(disc);                                         /* :123 / glsl:130 */
+}
+float orc_hit_sphere(const float cc[3], float radius, const float oo[3], const float dd[3])
+{
+    return (float)hit_sphere_t(cc, radius, oo, dd, 0);
 }
 
 /* hitBox, RayTracing.glsl:138-156, with a side per axis.  The shader reads one side,
@@ -279,9 +313,9 @@ float orc_hit_box3(const float cc[3], const float sides[3], const float oo[3], c
     }
     float best = INFINITY;                                           /* :146 */
     for (int k = 0; k < 3; ++k) {                                    /* :147 */
-        float px = fabsf(fmaf(d[0], t[k], o[0]));                    /* :148-149 */
-        float py = fabsf(fmaf(d[1], t[k], o[1]));
-        float pz = fabsf(fmaf(d[2], t[k], o[2]));
+        float px = fabsf(lfma(d[0], t[k], o[0]));                    /* :148-149 */
+        float py = fabsf(lfma(d[1], t[k], o[1]));
+        float pz = fabsf(lfma(d[2], t[k], o[2]));
         float inf_norm = gmax(px, gmax(py, pz));                     /* :150 */
         if (inf_norm < 0.5001f && inf_norm > 0.4999f && best > t[k]) /* :151 */
             best = t[k];
@@ -316,22 +350,26 @@ void orc_box_normal(const float cc[3], float scale, const float pp[3], float nn[
  * shape's 4x4 transformation (column-major): rotation in the upper-left 3x3, centre in
  * column 3.  As written there: the three slab distances are tried in axis order and the
  * FIRST whose point lies exactly on the cube's surface (infinity norm == 0.5) is the hit,
- * whether or not it is the nearest; divisions are IEEE.  Returns 1 and fills t and the
- * point in the cube's frame, else 0. */
+ * whether or not it is the nearest; divisions are IEEE.  The exact comparison makes the
+ * rounding of `originTransformed + directionTransformed * t` part of the result, so this
+ * routine never fuses: every product and sum is rounded on its own, in Eigen's order, as a
+ * C++ compiler without contraction evaluates :186-192 (with a fused multiply-add the point
+ * lands exactly on 0.5 far less often and most of the cube disappears).  Returns 1 and
+ * fills t and the point in the cube's frame, else 0. */
 int orc_hit_cube(const float m[16], const float oo[3], const float dd[3], float* t_out, float in_point[3])
 {
     float oc[3] = { oo[0] - m[12], oo[1] - m[13], oo[2] - m[14] };
     float o[3], d[3], t[3];
     for (int i = 0; i < 3; ++i) {                                      /* rotation * (orig - center), rotation * dir   :186-187 */
-        o[i] = fmaf(m[8 + i], oc[2], fmaf(m[4 + i], oc[1], m[i] * oc[0]));
-        d[i] = fmaf(m[8 + i], dd[2], fmaf(m[4 + i], dd[1], m[i] * dd[0]));
+        o[i] = (m[i] * oc[0] + m[4 + i] * oc[1]) + m[8 + i] * oc[2];
+        d[i] = (m[i] * dd[0] + m[4 + i] * dd[1]) + m[8 + i] * dd[2];
     }
     for (int i = 0; i < 3; ++i) {
         float sg = fsign(o[i]);                                        /* cwiseSign                                    :188 */
         t[i] = (0.5f - o[i] * sg) / (sg * d[i]);                       /*                                              :190 */
     }
     for (int k = 0; k < 3; ++k) {                                      /*                                              :191 */
-        float px = fmaf(d[0], t[k], o[0]), py = fmaf(d[1], t[k], o[1]), pz = fmaf(d[2], t[k], o[2]);   /* :192 */
+        float px = o[0] + d[0] * t[k], py = o[1] + d[1] * t[k], pz = o[2] + d[2] * t[k];               /* :192 */
         if (gmax(fabsf(px), gmax(fabsf(py), fabsf(pz))) == 0.5f) {     /*                                              :193 */
             *t_out = t[k];
             in_point[0] = px; in_point[1] = py; in_point[2] = pz;
@@ -392,11 +430,13 @@ static inline void box_sides(const orc_params* p, const orc_shape* s, float side
     sides[0] = s->m[0]; sides[1] = own ? s->m[5] : s->m[0]; sides[2] = own ? s->m[10] : s->m[0];
 }
 
-static float hit_shape(tracer* T, const orc_shape* s, const ray* r)
+/* Distances travel as doubles: the CPU tracer's HitRecord::t is one (scene.h:34).  In the recipe arithmetic and
+ * under the shader's rules every value is a float widened, which compares exactly as the float does. */
+static double hit_shape(tracer* T, const orc_shape* s, const ray* r)
 {
     float c[3] = { s->m[12], s->m[13], s->m[14] };
     float o[3] = { r->o.x, r->o.y, r->o.z }, d[3] = { r->d.x, r->d.y, r->d.z };
-    if (s->type == 0) { T->st.sphere_tests++; return orc_hit_sphere(c, s->m[0], o, d); }
+    if (s->type == 0) { T->st.sphere_tests++; return hit_sphere_t(c, s->m[0], o, d, T->p->semantics == ORC_SEM_CPU); }
     if (s->type == 1) {
         float sides[3]; box_sides(T->p, s, sides);
         T->st.box_tests++;
@@ -413,10 +453,10 @@ static float hit_shape(tracer* T, const orc_shape* s, const ray* r)
  * arguments of rayTracer.h:117 — `t_min < temp.t` compares the double 0.001
  * with a widened float, which holds exactly when t >= 0.001f.  GLSL:
  * RayTracing.glsl:212,226. */
-static inline int in_window(const orc_params* p, float t)
+static inline int in_window(const orc_params* p, double t)
 {
-    if (p->semantics == ORC_SEM_CPU) return t >= 0.001f && t < FLT_MAX;
-    return t < 1000.0f && t > 0.0001f;
+    if (p->semantics == ORC_SEM_CPU) return (t_lit ? 0.001 < t : t >= (double)0.001f) && t < (double)FLT_MAX;
+    return t < 1000.0 && t > (double)0.0001f;
 }
 
 /* Scene::hit (scene.h:232-255) / getClosestShapeIndex + getClosestTriangleIndex
@@ -424,13 +464,13 @@ static inline int in_window(const orc_params* p, float t)
  * a triangle replaces a shape only when strictly closer (RayTracing.glsl:271). */
 static int closest_hit(tracer* T, const ray* r, float* t_out)
 {
-    float best = INFINITY; int index = -1;
+    double best = INFINITY; int index = -1;
     for (uint32_t i = 0; i < T->n_shapes; ++i) {
-        float t = hit_shape(T, &T->shapes[i], r);
+        double t = hit_shape(T, &T->shapes[i], r);
         T->st.shape_tests++;
         if (in_window(T->p, t) && t < best) { best = t; index = (int)i; }
     }
-    float best_tri = INFINITY; int index_tri = -1;
+    double best_tri = INFINITY; int index_tri = -1;
     float o[3] = { r->o.x, r->o.y, r->o.z }, d[3] = { r->d.x, r->d.y, r->d.z };
     for (uint32_t i = 0; i < T->n_tris; ++i) {
         float t = orc_hit_triangle(&T->tris[i], o, d);
@@ -438,8 +478,8 @@ static int closest_hit(tracer* T, const ray* r, float* t_out)
         if (in_window(T->p, t) && t < best_tri) { best_tri = t; index_tri = (int)i; }
     }
     if (index < 0 && index_tri < 0) return -1;                        /* RayTracing.glsl:267 */
-    if (best_tri < best) { *t_out = best_tri; return (int)T->n_shapes + index_tri; }  /* :271 */
-    *t_out = best;
+    if (best_tri < best) { *t_out = (float)best_tri; return (int)T->n_shapes + index_tri; }  /* :271 */
+    *t_out = (float)best;                                             /* Ray::at(double) multiplies a float vector: narrowed there */
     return index;
 }
 
@@ -722,7 +762,10 @@ void orc_camera_ray(const float camera[21], const orc_params* p, uint32_t gx, ui
     pathrng key;
     orc_params q = *p;
     if (q.sample_mode != ORC_SAMPLE_JITTER && q.grid_n == 0) q.grid_n = isqrt_u32(q.first_sample + q.spp);
+    const int lit_before = t_lit;
+    t_lit = q.arith == ORC_ARITH_LITERAL;
     ray r = camera_ray(camera, &q, seed_key(p->seed), gx, gy, sample, &key);
+    t_lit = lit_before;
     origin[0] = r.o.x; origin[1] = r.o.y; origin[2] = r.o.z;
     dir[0] = r.d.x; dir[1] = r.d.y; dir[2] = r.d.z;
 }
@@ -790,6 +833,8 @@ int orc_render(const orc_shape* shapes, uint32_t n_shapes, const orc_triangle* t
         tracer T; memset(&T, 0, sizeof T);
         T.shapes = shapes; T.n_shapes = n_shapes; T.tris = tris; T.n_tris = n_tris;
         T.cam = camera; T.p = &q; T.seed_k = seed_key(q.seed);
+        const int lit_before = t_lit;                                  /* the flag is per thread: set it in every worker */
+        t_lit = q.arith == ORC_ARITH_LITERAL;
 #pragma omp for schedule(dynamic, 1)
         for (int64_t y = 0; y < (int64_t)q.height; ++y) {
             if (!row_in_shard(&q, (uint32_t)y)) continue;
@@ -812,6 +857,7 @@ int orc_render(const orc_shape* shapes, uint32_t n_shapes, const orc_triangle* t
                 }
             }
         }
+        t_lit = lit_before;
 #pragma omp critical
         stats_add(&total, &T.st);
     }
@@ -828,6 +874,8 @@ int orc_trace(const orc_shape* shapes, uint32_t n_shapes, const orc_triangle* tr
     tracer T; memset(&T, 0, sizeof T);
     T.shapes = shapes; T.n_shapes = n_shapes; T.tris = tris; T.n_tris = n_tris;
     T.cam = camera; T.p = &q; T.seed_k = seed_key(q.seed);
+    const int lit_before = t_lit;
+    t_lit = q.arith == ORC_ARITH_LITERAL;
     for (uint32_t y = 0; y < q.height; ++y)
         for (uint32_t x = 0; x < q.width; ++x) {
             size_t base = ((size_t)y * q.width + x) * q.max_depth;
@@ -835,6 +883,7 @@ int orc_trace(const orc_shape* shapes, uint32_t n_shapes, const orc_triangle* tr
             T.trace_hit = hit_index + base; T.trace_mat = material_id + base;
             (void)path_color(&T, x, y, sample);
         }
+    t_lit = lit_before;
     return 0;
 }
 

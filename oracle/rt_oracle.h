@@ -47,6 +47,13 @@ enum { ORC_COLOR_AS_WRITTEN = 0, ORC_COLOR_FORWARD = 1 };
  *          literally (uses libm; only for the statistical cross-check). */
 enum { ORC_UNIT_DIRECT = 0, ORC_UNIT_GAUSS = 1 };
 
+/* Which arithmetic evaluates the reference's expressions (see rt_oracle.c):
+ * RECIPE  = the fixed recipes the HIP kernels repeat bit for bit (explicit FMAs, Newton reciprocal and reciprocal
+ *           root, polynomial sin/cos);
+ * LITERAL = the source text as a compiler without contraction evaluates it: no FMA, IEEE divide, v / sqrt(v.v),
+ *           libm sinf/cosf, Sphere::hit's distance in double.  Used only to state how far RECIPE is from the text. */
+enum { ORC_ARITH_RECIPE = 0, ORC_ARITH_LITERAL = 1 };
+
 typedef struct {
     uint32_t width, height;
     uint32_t spp, first_sample, max_depth, grid_n;
@@ -59,6 +66,7 @@ typedef struct {
     int32_t  threads;                               /* <=0: all cores                  */
     uint32_t rng;                                   /* ORC_RNG_HASH / ORC_RNG_GLSL     */
     const float* triangle_colors;                   /* NULL, or rgb per triangle (replaces triangle_albedo) */
+    uint32_t arith;                                 /* ORC_ARITH_RECIPE / ORC_ARITH_LITERAL */
 } orc_params;
 
 typedef struct {
@@ -89,7 +97,9 @@ void orc_resolve(const uint32_t* accum, uint32_t width, uint32_t height,
 void orc_convert(uint32_t* accum, float* image_rgba, uint32_t width, uint32_t height,
                  uint32_t samples_in_accum, uint32_t semantics, uint32_t n_samples);
 
-/* Pieces exposed for known-answer tests. */
+/* Pieces exposed for known-answer tests.  They use the calling thread's arithmetic, ORC_ARITH_RECIPE unless
+ * orc_set_arith(ORC_ARITH_LITERAL) was called on it. */
+void     orc_set_arith(int arith);
 uint32_t orc_hash32(uint32_t x);
 uint32_t orc_path_key(uint64_t seed, uint32_t pixel_index, uint32_t sample);
 float    orc_draw(uint32_t key, uint32_t index);

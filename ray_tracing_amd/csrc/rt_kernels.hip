@@ -303,12 +303,18 @@ RT_DEV V3 box_normal(V3 c, float rx, float ry, float rz, V3 p)
 // Cube::hit, src/cpu_version/scene.h:185-204, on the rows {R(i,*), c_i} of a cube.  As
 // written there: the three slab distances are tried in axis order and the first whose point
 // lies exactly on the surface (infinity norm == 0.5) is the hit, nearest or not; IEEE
-// divisions.  Returns the distance (+inf without a hit) and the point in the cube's frame.
+// divisions.  The exact comparison makes the rounding of origin + direction * t part of the
+// result, so nothing here is fused: every product and sum is rounded on its own, in Eigen's
+// order, as a C++ compiler without contraction evaluates those lines (the file is compiled
+// with -ffp-contract=off; with a fused multiply-add the point lands exactly on 0.5 far less
+// often and most of the cube disappears).  Returns the distance (+inf without a hit) and the
+// point in the cube's frame.
+RT_DEV float dot_unfused(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 RT_DEV float hit_cube(float4 r0, float4 r1, float4 r2, V3 o, V3 d, V3& in_point)
 {
     const V3 oc = v3(o.x - r0.w, o.y - r1.w, o.z - r2.w);
-    const V3 ob = v3(dot(xyz(r0), oc), dot(xyz(r1), oc), dot(xyz(r2), oc));
-    const V3 db = v3(dot(xyz(r0), d), dot(xyz(r1), d), dot(xyz(r2), d));
+    const V3 ob = v3(dot_unfused(xyz(r0), oc), dot_unfused(xyz(r1), oc), dot_unfused(xyz(r2), oc));
+    const V3 db = v3(dot_unfused(xyz(r0), d), dot_unfused(xyz(r1), d), dot_unfused(xyz(r2), d));
     const V3 sg = v3(sign_(ob.x), sign_(ob.y), sign_(ob.z));
     float t[3];
     t[0] = (0.5f - ob.x * sg.x) / (sg.x * db.x);
@@ -319,7 +325,7 @@ RT_DEV float hit_cube(float4 r0, float4 r1, float4 r2, V3 o, V3 d, V3& in_point)
     in_point = v3(0, 0, 0);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float px = fma_(db.x, t[k], ob.x), py = fma_(db.y, t[k], ob.y), pz = fma_(db.z, t[k], ob.z);
+        const float px = ob.x + db.x * t[k], py = ob.y + db.y * t[k], pz = ob.z + db.z * t[k];
         const bool on = gmax(__builtin_fabsf(px), gmax(__builtin_fabsf(py), __builtin_fabsf(pz))) == 0.5f;
         const bool first = on && !found;
         hit_t = first ? t[k] : hit_t;
