@@ -87,18 +87,38 @@ RT_DEV float rcp_nr(float x)
     }
     return y;
 }
-// Correctly rounded sqrt: v_sqrt_f32 (within 1 ulp) plus a residual test against each
-// neighbour — the sequence hipcc emits for sqrtf, without its range scaling.  For
-// arguments in (0, 2^-96), where the residuals go subnormal, the result is only a
-// tiny number of the right order; every caller below tolerates that (see them).
+// v_mul_legacy_f32: a product in which 0 times anything — an infinity too — is 0.  The compiler
+// does not see into the asm, so the wait state a vector instruction needs before it reads the
+// result of a transcendental one (v_rsq_f32 below) is written out: without it some lanes read
+// the register before the result is there.
+RT_DEV float mul_legacy_after_trans(float a, float b)
+{
+    float r;
+    asm("s_nop 0\n\tv_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+RT_DEV float mul_legacy(float a, float b)
+{
+    float r;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// Correctly rounded sqrt from ONE transcendental instruction: y = v_rsq_f32(x) (within 1 ulp),
+// g = x*y, and one correction step s = g + (x - g*g) * y/2 whose residual is exact (fma).
+// tools/sqrt_exact.hip runs this sequence over every binary32 input on the chip: the result is
+// the IEEE square root for all x in [2^-96, FLT_MAX] and for x = 0 (the two legacy products
+// carry 0 * inf through as 0).  For arguments in (0, 2^-96), where the residual goes
+// subnormal, the result is only a tiny number of the right order; every caller below
+// tolerates that (see them).  Negative x gives NaN, +inf gives 0 (no caller can pass it).
+// Six instructions and 19 issue cycles against nine and 34 for v_sqrt_f32 with a residual test
+// against each neighbour, and 53 cycles for the compiler's sqrtf.
 RT_DEV float sqrt_rn(float x)
 {
-    float s = __builtin_amdgcn_sqrtf(x);
-    float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
-    float rm = fma_(-sm, s, x), rp = fma_(-sp, s, x);
-    s = (rm <= 0.0f) ? sm : s;
-    s = (rp > 0.0f) ? sp : s;
-    return s;
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = mul_legacy_after_trans(x, y);
+    const float h = 0.5f * y;
+    const float r = fma_(-g, g, x);
+    return g + mul_legacy(r, h);
 }
 RT_DEV V3 cross(V3 a, V3 b)
 {
@@ -249,6 +269,9 @@ RT_DEV void take_if_closer(Best& best, uint32_t key, uint32_t id, bool also = tr
 
 // Sphere::hit (src/cpu_version/scene.h:115-128) = hitSphere
 // (RayTracing.glsl:118-132).  s = centre.xyz, radius^2.
+// Spheres are tested in upload order, so inside their scan the reference's own rule suffices: a
+// later sphere replaces the best only by a strictly smaller key (scene.h:237, glsl:212) — one
+// 32-bit compare; the index joins the comparison only against boxes, cubes and triangles.
 template <int SEM>
 RT_DEV void test_sphere(float4 s, uint32_t shape_id, V3 o, V3 d, Best& best)
 {
@@ -263,7 +286,10 @@ RT_DEV void test_sphere(float4 s, uint32_t shape_id, V3 o, V3 d, Best& best)
     // last bit, or lies below the window.)
     if (!__any(b < 0.0f && disc >= 0.0f)) return;
     float t = -b - sqrt_rn(disc);
-    take_if_closer(best, __float_as_uint(t) - Window<SEM>::tmin, shape_id);
+    const uint32_t key = __float_as_uint(t) - Window<SEM>::tmin;
+    const bool take = key < best.key;
+    best.key = take ? key : best.key;
+    best.id = take ? shape_id : best.id;
 }
 
 // hitBox, RayTracing.glsl:138-156.  bx = centre.xyz, 1/side along x; iy, iz = 1/side along
@@ -587,7 +613,8 @@ void trace_kernel(const TraceParams P,
         //      (glsl:271) and the first of equal distances stays.
         // "Nothing yet" = (last accepted distance, NONE): a hit at that very distance still wins by its index,
         // anything from `far` on loses (t < FLT_MAX, scene.h:237; distance < 1000, glsl:212).
-        Best best = { Window<SEM>::far - 1u - Window<SEM>::tmin, NONE };
+        // The spheres' scan compares keys only and starts one key further out: `far` itself still loses.
+        Best best = { Window<SEM>::far - Window<SEM>::tmin, NONE };
         for (uint32_t c = 0; c < n_chunks; ++c) {
             const float4 s0 = sph[4u * c], s1 = sph[4u * c + 1u], s2 = sph[4u * c + 2u], s3 = sph[4u * c + 3u];
             const float4 ids = sid[c];
@@ -596,6 +623,7 @@ void trace_kernel(const TraceParams P,
             test_sphere<SEM>(s2, __float_as_uint(ids.z), o, d, best);
             test_sphere<SEM>(s3, __float_as_uint(ids.w), o, d, best);
         }
+        if (HAS_QUEUES || HAS_CUBE) best.key = (best.id == NONE) ? Window<SEM>::far - 1u - Window<SEM>::tmin : best.key;
         // The lanes still tracing, and this lane's place among them: they share the queued tests.
         uint32_t n_live = 64u, lane_rank = lane;
         if (HAS_QUEUES) {
@@ -660,7 +688,7 @@ void trace_kernel(const TraceParams P,
                 take_if_closer(best, (uint32_t)(f >> 32), (uint32_t)f);
                 found[lane] = NOTHING;
             }
-        } else {
+        } else if (HAS_QUEUES) {                                  // a scene with boxes never runs the instance without queues
             for (uint32_t i = 0; i < n_box; ++i) {
                 const float4 bx = box[3u * i];
                 const float4 bx1 = box[3u * i + 1u];
@@ -831,7 +859,7 @@ void trace_kernel(const TraceParams P,
         const float t_hit = __uint_as_float(best_key + Window<SEM>::tmin);
         const V3 p = madd(t_hit, d, o);                               // Ray::at / glsl:239
         if (best_id != NONE) {
-            if (best_id >= n_shapes) {
+            if (HAS_QUEUES && best_id >= n_shapes) {
                 V3 a = xyz(tri[4u * slot_of[best_id - n_shapes] + 1u]);
                 n = a * sign_(-dot(d, a));                            // glsl:165-167,272
                 att = v3(P.tri_albedo[0], P.tri_albedo[1], P.tri_albedo[2]);
@@ -843,8 +871,10 @@ void trace_kernel(const TraceParams P,
                 const uint32_t stype = tag >> 16;
                 type = tag & 0xffffu;
                 att = xyz(r1);
-                if (stype == 0u) n = normalize(v3(p.x - r0.x, p.y - r0.y, p.z - r0.z));      // scene.h:130-132
-                else if (stype == 1u) { const float4 r3 = rec[4u * best_id + 3u]; n = box_normal(xyz(r0), rec[4u * best_id + 2u].z, r3.z, r3.w, p); }
+                // An instance without boxes, triangles and cubes is launched only for scenes in which every shape that can
+                // be hit is a sphere.
+                if ((!HAS_QUEUES && !HAS_CUBE) || stype == 0u) n = normalize(v3(p.x - r0.x, p.y - r0.y, p.z - r0.z));      // scene.h:130-132
+                else if (HAS_QUEUES && stype == 1u) { const float4 r3 = rec[4u * best_id + 3u]; n = box_normal(xyz(r0), rec[4u * best_id + 2u].z, r3.z, r3.w, p); }
                 else if (HAS_CUBE && stype == 3u) {
                     // rotation^T * normalAt(inPoint), scene.h:150-164,196: the row of the rotation that
                     // belongs to the largest |coordinate| of the point in the cube's frame (first of
