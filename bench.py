@@ -320,6 +320,9 @@ def main():
                        "shard": args.shard, "spp_total": parallel.total_samples(shard), "device": info["name"]},
             "mrays_per_s": round(stats["segments"] * world / (elapsed / args.steps) / 1e6, 2),
             "segments_per_sample": round(stats["segments"] / max(1, stats["samples"]), 4),
+            # share of the lane-iterations of the bounce loop that traced a segment (the rest: lanes whose pixel had
+            # no samples left while their wave went on)
+            "lane_use": round(stats["segments"] / max(1, 64 * stats["wave_iterations"]), 4),
             "cold_first_frame_ms": None if cold_ms is None else round(cold_ms, 4),
             "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,

@@ -84,7 +84,8 @@ struct rt_ctx {
     // Staging for entry points that return data to host memory (rt_resolve, rt_trace_debug): grown on demand, kept.
     void* d_stage = nullptr;             size_t stage_cap = 0;
     // Switches for measurements, read from the environment once, when the context is created.
-    bool env_group_waves_1 = false, env_no_tile_order = false, env_no_slices = false, env_mesh_in_global = false, env_no_probe = false;
+    uint32_t group_waves = 4;           // waves per workgroup (RT_GROUP_WAVES: 1 .. 8, for measurements)
+    bool env_no_tile_order = false, env_no_slices = false, env_mesh_in_lds = false, env_no_probe = false;
 };
 
 static thread_local std::string g_create_error;
@@ -343,10 +344,10 @@ static int plan_blob(rt_ctx* ctx, BlobPlan& B)
     L.inv_off = staged_words;
     L.total_words = L.inv_off + (n_tris + 3u) / 4u;
     B.colors = !ctx->tri_colors.empty() && ctx->tri_colors.size() == 3u * (size_t)n_tris;
-    const uint32_t wave_words = (n_tris || n_box) ? rtd::LDS_WAVE_WORDS_PER_GROUP : 0u;     // queues and slots of the spread tests
-    if ((size_t)(L.node_off[rtd::TREE_LEVELS - 1u] + (n_tris ? rtd::LDS_WAVE_WORDS_PER_GROUP_GLOBAL : wave_words)) * 16u > rtd::LDS_MAX_BYTES)
+    const uint32_t wave_words = (n_tris || n_box) ? rtd::lds_wave_words(ctx->group_waves, false) : 0u;     // queues and slots of the spread tests
+    if ((size_t)(L.node_off[rtd::TREE_LEVELS - 1u] + (n_tris ? rtd::lds_wave_words(ctx->group_waves, true) : wave_words)) * 16u > rtd::LDS_MAX_BYTES)
         return fail(ctx, RT_ERR_INVALID_ARG, "scene: %u shapes need more than the %u-byte LDS stage", n_shapes, rtd::LDS_MAX_BYTES);
-    if ((size_t)(staged_words + wave_words) * 16u <= rtd::LDS_MAX_BYTES && !ctx->env_mesh_in_global) { L.lds_words = staged_words; L.tri_in_lds = 1; }
+    if ((size_t)(staged_words + wave_words) * 16u <= rtd::LDS_MAX_BYTES && ctx->env_mesh_in_lds) { L.lds_words = staged_words; L.tri_in_lds = 1; }
     else { L.lds_words = L.node_off[rtd::TREE_LEVELS - 1u]; L.tri_in_lds = 0; }     // the mesh and its tree stay in global memory
     // Per-triangle albedo: read only at a hit, so it stays in global memory behind everything else.
     if (B.colors) { L.tcol_off = L.total_words; L.total_words += n_tris; }
@@ -507,10 +508,10 @@ int rt_create(rt_ctx** out, const rt_config* cfg)
     e = rtd::scratch_for_device(c.device, &ctx->d_scratch);
     if (e != hipSuccess) { (void)hipFree(ctx->d_stats); delete ctx; return fail(nullptr, RT_ERR_HIP, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e)); }
     auto env_on = [](const char* name) { const char* v = getenv(name); return v && *v && strcmp(v, "0") != 0; };
-    ctx->env_group_waves_1 = getenv("RT_GROUP_WAVES") && atoi(getenv("RT_GROUP_WAVES")) == 1;
+    if (const char* gw = getenv("RT_GROUP_WAVES")) { const int n = atoi(gw); if (n >= 1 && n <= (int)rtd::MAX_GROUP_WAVES) ctx->group_waves = (uint32_t)n; }
     ctx->env_no_tile_order = env_on("RT_NO_TILE_ORDER");
     ctx->env_no_slices = env_on("RT_NO_SLICES");
-    ctx->env_mesh_in_global = env_on("RT_MESH_IN_GLOBAL");
+    ctx->env_mesh_in_lds = env_on("RT_MESH_IN_LDS");
     ctx->env_no_probe = env_on("RT_NO_PROBE");
     *out = ctx;
     return RT_OK;
@@ -684,7 +685,7 @@ static int fill_params(rt_ctx* ctx, rtd::TraceParams& P, uint32_t width, uint32_
     // Four waves per workgroup share one staged copy of the scene.  Single-wave workgroups (RT_GROUP_WAVES=1, for
     // measurements) free their slot the moment the wave ends: no faster on the four-sphere scene (1.34 against
     // 1.36 ms), 2.2 times slower on the mesh scene, where the staged scene then limits the waves per CU.
-    P.group_waves = ctx->env_group_waves_1 ? 1u : 4u;
+    P.group_waves = ctx->group_waves;
     // tile_plan_kernel counts the entries of its three classes in fields of 21 bits, and a sliced frame has up to
     // twice as many entries as tiles.
     RT_REQUIRE(ctx, (uint64_t)P.tiles_x * P.tiles_y < (1u << 20), "render: more than 2^20 tiles of 16x16 pixels");

@@ -66,7 +66,8 @@ struct TraceParams {
     uint32_t owned_rows;       // rows of this shard
     uint32_t trace_sample;     // TRACE launches: the one sample to follow
     uint32_t tiles_x, tiles_y; // 16x16-pixel tiles covering width x owned_rows
-    uint32_t group_waves;      // waves per workgroup: 4 (one 16x16 tile) or 1 (one 8x8 quarter of it)
+    uint32_t group_waves;      // waves per workgroup, 1 .. MAX_GROUP_WAVES; wave q of the launch traces quarter q & 3 of plan entry q >> 2
+    uint32_t plan_entries;     // entries (16x16 tiles, or slices of one) in this launch's plan
     uint32_t rng_mode;         // 0 counter hash, 1 the shader's random() (RayTracing.glsl:44-51)
     uint32_t glsl_seed32;      // low word of the seed: the shader's `time` is (this + frame) / 10000
     float    inv_w, inv_h;     // 1 / width, 1 / height (RayTracing.glsl:9 divides the invocation id by them)
@@ -79,6 +80,7 @@ enum { ST_SAMPLES = 0, ST_SEGMENTS, ST_DIFFUSE, ST_SPECULAR, ST_TERMINAL, ST_TRI
 constexpr int TILE_W = 16;     // pixels per workgroup in x (two 8-wide wave tiles)
 constexpr int TILE_H = 16;     // and in y
 constexpr int BLOCK = 256;
+constexpr uint32_t MAX_GROUP_WAVES = 8;   // instances with queues may be launched with up to this many waves per workgroup
 
 // LDS a workgroup may use for the staged scene.  8 workgroups of 4 waves fill a
 // CU's 32 wave slots; 160 KiB / 8 = 20 KiB each keeps that occupancy.  Scenes
@@ -108,9 +110,14 @@ static_assert((64u / TREE_FAN - 1u) + (SPREAD_BELOW - 1u) <= NODE_STACK_STAGED, 
 static_assert((64u / TREE_FAN - 1u) + (SPREAD_BELOW - 1u) + (TREE_LEVELS - 2u) * (64u - 64u / TREE_FAN) + 64u <= NODE_STACK_GLOBAL,
               "the node stack of a mesh in global memory overflows");
 static_assert(TREE_LEVELS == 4u, "stack entries carry two bits of level, the walk has four nested loops");
-constexpr uint32_t WAVE_LDS_WORDS = (QUEUE_ENTRIES * 4u + 64u * 8u + NODE_STACK_STAGED * 4u) / 16u;
-constexpr uint32_t WAVE_LDS_WORDS_GLOBAL = (QUEUE_ENTRIES * 4u + 64u * 8u + NODE_STACK_GLOBAL * 4u) / 16u;
-constexpr uint32_t LDS_WAVE_WORDS_PER_GROUP = (BLOCK / 64) * WAVE_LDS_WORDS;
-constexpr uint32_t LDS_WAVE_WORDS_PER_GROUP_GLOBAL = (BLOCK / 64) * WAVE_LDS_WORDS_GLOBAL;
+// Behind them: the sums of the wave's 64 pixels, three 32-bit words each, while the wave's lanes share its paths.
+#ifndef RT_POOL
+#define RT_POOL 1
+#endif
+constexpr uint32_t POOL_SUM_BYTES = RT_POOL ? 3u * 64u * 4u : 0u;
+constexpr uint32_t WAVE_LDS_WORDS = (QUEUE_ENTRIES * 4u + 64u * 8u + NODE_STACK_STAGED * 4u + POOL_SUM_BYTES) / 16u;
+constexpr uint32_t WAVE_LDS_WORDS_GLOBAL = (QUEUE_ENTRIES * 4u + 64u * 8u + NODE_STACK_GLOBAL * 4u + POOL_SUM_BYTES) / 16u;
+// The 16-byte words a workgroup of `group_waves` waves needs behind the staged scene.
+constexpr uint32_t lds_wave_words(uint32_t group_waves, bool mesh_in_global) { return group_waves * (mesh_in_global ? WAVE_LDS_WORDS_GLOBAL : WAVE_LDS_WORDS); }
 
 }  // namespace rtd

@@ -42,6 +42,21 @@ namespace rtd {
 #ifndef RT_COST_CLOCK
 #define RT_COST_CLOCK 1
 #endif
+// Waves per SIMD the instances with queues are built for (their register budget: 512 / this, in steps of 8).
+#ifndef RT_QUEUE_WAVES
+#define RT_QUEUE_WAVES 7
+#endif
+// Measurement build (-DRT_PHASE_CLOCKS=1): the timeline record of a wave holds, instead of its start and end, the
+// shader clocks / 16 its loop spent in the sphere scan, the boxes and cubes, the triangle tree, and the rest
+// (surface, draws, new direction); tools/phase_clocks.py sums them.
+#ifndef RT_PHASE_CLOCKS
+#define RT_PHASE_CLOCKS 0
+#endif
+#if RT_PHASE_CLOCKS
+#define RT_PHASE_MARK(k) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); phase_clk[k] += now_ - phase_t; phase_t = now_; }
+#else
+#define RT_PHASE_MARK(k)
+#endif
 struct V3 { float x, y, z; };
 constexpr uint32_t WORK_NONE = 0xffffffffu;      // a plan entry without work
 
@@ -445,11 +460,11 @@ RT_DEV uint32_t quantise(float c)
 // two random draws and the normalisation of the new direction — are issued
 // once for the whole wave, whether a lane is bouncing or starting a sample.
 template <int SEM, int GEO, int MODE>
-__global__ __launch_bounds__(BLOCK)
+__global__ __launch_bounds__((GEO & 3) != 0 ? 64 * MAX_GROUP_WAVES : BLOCK)
 // Spheres only: 64 registers, eight waves per SIMD.  With boxes or a mesh the staged scene and the wave's queues
 // leave room for six workgroups per CU at most, so those instances may use the registers of six waves per SIMD.
 // Sphere scenes with dielectrics, cubes or triangle colours need a few registers more than 64: seven waves, no spills.
-__attribute__((amdgpu_waves_per_eu((GEO & 3) != 0 ? 6 : ((GEO & 4) != 0 ? 7 : 8), 8)))
+__attribute__((amdgpu_waves_per_eu((GEO & 3) != 0 ? RT_QUEUE_WAVES : ((GEO & 4) != 0 ? 7 : 8), 8)))
 void trace_kernel(const TraceParams P,
                   const float4* __restrict__ blob,
                   uint32_t* __restrict__ accum,
@@ -461,6 +476,9 @@ void trace_kernel(const TraceParams P,
 {
     constexpr bool STATS = MODE == 1, TRACE = MODE == 2;
     constexpr bool COST_CLOCK = RT_COST_CLOCK != 0;        // a tile's cost: shader clocks of its slowest wave, not loop iterations
+    // The 64 x (samples) paths of a wave's 8x8 tile are one pool that its lanes draw from (shader rules, whose integer
+    // sums take any order): see "pool" below.
+    constexpr bool POOL = RT_POOL != 0 && SEM == 1 && !TRACE && (GEO & 3) != 0;
     constexpr bool HAS_QUEUES = (GEO & 3) != 0, TRI_GLOBAL = (GEO & 3) == 2, SPREAD_BOXES = HAS_QUEUES, HAS_CUBE = SEM == 0 && (GEO & 4) != 0, HAS_GLASS = (GEO & 4) != 0, HAS_TCOL = (GEO & 4) != 0, RNG_GLSL = (GEO & 8) != 0;
     extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x;
@@ -484,10 +502,12 @@ void trace_kernel(const TraceParams P,
     // A workgroup is the four waves of one entry, or (P.group_waves = 1) a single wave, four consecutive
     // workgroups sharing an entry.
     const uint32_t q = blockIdx.x * P.group_waves + (tid >> 6);
-    const uint32_t unit = tile_order ? tile_order[q >> 2] : (n_tiles - 1u - (q >> 2));
-    if (unit == WORK_NONE) return;                       // uniform over the workgroup
+    const uint32_t unit = (q >> 2) < P.plan_entries ? (tile_order ? tile_order[q >> 2] : (n_tiles - 1u - (q >> 2))) : WORK_NONE;
+    // Workgroups of four waves hold one entry; larger ones may hold entries with and without work.
+    if (P.group_waves <= 4u ? unit == WORK_NONE : __syncthreads_count(unit != WORK_NONE) == 0) return;
     for (uint32_t i = tid; i < P.scene.lds_words; i += blockDim.x) lds[i] = blob[i];
     __syncthreads();
+    if (unit == WORK_NONE) return;                       // uniform over the wave; no barrier follows
     {
     const uint32_t sub = q & 3u;
     const uint32_t tile = unit & 0xffffffu;
@@ -523,16 +543,18 @@ void trace_kernel(const TraceParams P,
 
     // Origin of the camera ray of `sample`: RayTracing.glsl:296 (jitter, from
     // two draws) or renderPixel<N>, src/cpu_version/rayTracer.h:92-101 (grid).
+    V3 pcur = pc;                      // of the pixel this lane is tracing (POOL: not always its own)
+    uint32_t cgx = gx, cgy = gy;
     auto camera_origin = [&](uint32_t smp, float u1, float u2) -> V3 {
         if (P.sample_mode == 0u) {
             float s1 = step * u1, s2 = step * u2;
-            return madd(-s2, cam_up, madd(s1, cam_right, pc));
+            return madd(-s2, cam_up, madd(s1, cam_right, pcur));
         }
         const uint32_t N = P.grid_n;
         const uint32_t i = (smp / N) % N, j = smp % N;
         const float step_size = step / (float)(N + 1u);
         const V3 ups = cam_up * step_size, rs = cam_right * step_size;
-        V3 org = pc - ups * (float)i;
+        V3 org = pcur - ups * (float)i;
         if (P.sample_mode == 2u) {
             for (uint32_t jj = 0; jj <= j; ++jj) {
                 V3 inc = rs * (float)jj;
@@ -550,7 +572,7 @@ void trace_kernel(const TraceParams P,
     auto glsl_seed = [&](uint32_t smp) -> V3 {
         const uint32_t frame = smp / 100u, lx = smp % 10u, ly = (smp / 10u) % 10u;
         const float time = (float)(P.glsl_seed32 + frame) * 0.0001f;
-        return v3(time + (float)(10u * gx + lx) * P.inv_w, time + (float)(10u * gy + ly) * P.inv_h, time);
+        return v3(time + (float)(10u * cgx + lx) * P.inv_w, time + (float)(10u * cgy + ly) * P.inv_h, time);
     };
     // The two draws that start sample `smp`: sub-pixel jitter, first draw with `right`.
     auto start_draws = [&](uint32_t smp, uint32_t k, V3& state, float& a, float& b) {
@@ -603,6 +625,23 @@ void trace_kernel(const TraceParams P,
     uint32_t iterations = 0;           // of this lane
     const unsigned long long t_start = (!TRACE && trace_hit) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const unsigned long long c_start = (STATS || COST_CLOCK) ? __builtin_amdgcn_s_memtime() : 0ull;
+    // Pool.  A lane that walks the samples of its own pixel one after the other is done when ITS pixel is, and waits
+    // for the wave's costliest pixel: with sample ranges cut into slices of 16 a third of the lane-iterations on the
+    // mesh scene were spent waiting.  Under the shader's rules a pixel's sum is an integer sum and takes its terms in
+    // any order, so the wave's paths — item k*64 + p = sample k of the pixel of lane p — are handed out in item order
+    // to whichever lane is free: a lane whose path ends takes the next item (a count over the ended lanes, no
+    // atomics), fetches that pixel's ray constants from the pixel's home lane across the wave, and adds the path's
+    // colour to the pixel's sum in LDS.  The home lane writes the sums out at the end.  Waves of tiles that stick out
+    // of the frame keep the own-pixel order (their invalid lanes are not in the loop and cannot serve constants).
+    const uint32_t sample_begin = sample;
+    const uint32_t n_items = 64u * (sample_end - sample_begin);
+    const bool pool_on = POOL && __ballot(valid) == ~0ull;
+    uint32_t item = lane, next_item = 64u, cur_p = lane;
+    uint32_t* const pool_acc = node_stack + (TRI_GLOBAL ? NODE_STACK_GLOBAL : NODE_STACK_STAGED);   // [3][64]
+    if (POOL) { pool_acc[lane] = 0u; pool_acc[64u + lane] = 0u; pool_acc[128u + lane] = 0u; }
+#if RT_PHASE_CLOCKS
+    uint32_t phase_clk[4] = { 0u, 0u, 0u, 0u }, phase_t = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
     while (alive) {
         ++iterations;
         // ---- closest hit: Scene::hit (scene.h:232-255) /
@@ -624,6 +663,7 @@ void trace_kernel(const TraceParams P,
             test_sphere<SEM>(s3, __float_as_uint(ids.w), o, d, best);
         }
         if (HAS_QUEUES || HAS_CUBE) best.key = (best.id == NONE) ? Window<SEM>::far - 1u - Window<SEM>::tmin : best.key;
+        RT_PHASE_MARK(0)
         // The lanes still tracing, and this lane's place among them: they share the queued tests.
         uint32_t n_live = 64u, lane_rank = lane;
         if (HAS_QUEUES) {
@@ -703,6 +743,7 @@ void trace_kernel(const TraceParams P,
                 take_if_closer(best, __float_as_uint(t) - Window<SEM>::tmin, __float_as_uint(cub[4u * i + 3u].x));
             }
         }
+        RT_PHASE_MARK(1)
         // Triangles: walk the four-level bounding-sphere tree with the whole wave; a subtree is entered when the
         // ray of any live lane can touch its sphere.  At a leaf only the lanes whose rays touch it have any business
         // with its triangles — typically a few of the 64, since bounce rays share little — so they do not test
@@ -849,6 +890,7 @@ void trace_kernel(const TraceParams P,
                 }
             }
         }
+        RT_PHASE_MARK(2)
         const uint32_t best_key = best.key, best_id = best.id;
         if (STATS) { ++n_segments; }
 
@@ -915,21 +957,52 @@ void trace_kernel(const TraceParams P,
 
         // Two draws per lane: the bounce's pair, or — for a lane that starts a
         // sample — the jitter pair of the new sample.
+        uint32_t new_item = 0u;
+        if (POOL) {
+            const unsigned long long em = __ballot(ended);
+            new_item = pool_on ? next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u)) : item + 64u;
+            next_item += (uint32_t)__popcll(em);
+        }
         if (ended) {
             if (STATS) ++n_terminal;
             if (SEM == 0) {
                 acc0 = __float_as_uint(__uint_as_float(acc0) + color.x);   // rayTracer.h:101
                 acc1 = __float_as_uint(__uint_as_float(acc1) + color.y);
                 acc2 = __float_as_uint(__uint_as_float(acc2) + color.z);
+            } else if (POOL) {
+                atomicAdd(&pool_acc[cur_p], quantise(color.x));            // glsl:301-307
+                atomicAdd(&pool_acc[64u + cur_p], quantise(color.y));
+                atomicAdd(&pool_acc[128u + cur_p], quantise(color.z));
             } else {
                 acc0 += quantise(color.x);                                 // glsl:301-307
                 acc1 += quantise(color.y);
                 acc2 += quantise(color.z);
             }
-            ++sample;
-            alive = sample < sample_end;
-            key += SAMPLE_STEP;                                            // path_key(h1, sample)
+            if (POOL) {
+                item = new_item;
+                cur_p = item & 63u;
+                sample = sample_begin + (item >> 6);
+                alive = item < n_items;
+            } else {
+                ++sample;
+                alive = sample < sample_end;
+                key += SAMPLE_STEP;                                        // path_key(h1, sample)
+            }
             if (STATS && alive) ++n_samples;
+        }
+        if (POOL) {
+            // the constants of the pixel a lane goes on with, from that pixel's home lane (every lane reads: a read
+            // across the wave cannot sit in a branch; lanes in mid-path read their own pixel's and drop them)
+            const int from = (int)(cur_p << 2);
+            const V3 npc = v3(__uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(pc.x))),
+                              __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(pc.y))),
+                              __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(pc.z))));
+            const uint32_t nh1 = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)h1);
+            if (RNG_GLSL) {
+                const uint32_t ngx = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)gx), ngy = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)gy);
+                cgx = ended ? ngx : cgx; cgy = ended ? ngy : cgy;
+            }
+            if (ended) { pcur = npc; key = nh1 + sample * SAMPLE_STEP; }
         }
         float u1, u2;
         if (RNG_GLSL) {
@@ -1006,9 +1079,11 @@ void trace_kernel(const TraceParams P,
         }
         const V3 nd = normalize(v);
         d = v3(raw_dir ? v.x : nd.x, raw_dir ? v.y : nd.y, raw_dir ? v.z : nd.z);   // per component: a struct select goes through scratch memory
+        RT_PHASE_MARK(3)
     }
 
     if (!TRACE && valid) {
+        if (POOL) { acc0 += pool_acc[lane]; acc1 += pool_acc[64u + lane]; acc2 += pool_acc[128u + lane]; }
         if (CAN_SLICE && n_slices != 1u) {
             atomicAdd(acc_ptr, acc0); atomicAdd(acc_ptr + 1, acc1); atomicAdd(acc_ptr + 2, acc2);   // integer sums: any order
         } else {
@@ -1027,6 +1102,10 @@ void trace_kernel(const TraceParams P,
         rec4[2] = (int32_t)((((uint32_t)(__builtin_amdgcn_s_memtime() - c_start)) >> 4) |                       // shader clocks / 16
                             (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 28));                      // XCC_ID
         rec4[3] = (int32_t)iterations;
+#if RT_PHASE_CLOCKS
+        rec4[0] = (int32_t)(phase_clk[0] >> 4); rec4[1] = (int32_t)(phase_clk[1] >> 4);
+        rec4[2] = (int32_t)(phase_clk[2] >> 4) | (rec4[2] & (int32_t)0xf0000000); rec4[3] = (int32_t)(phase_clk[3] >> 4);
+#endif
     }
     if (STATS) {
         // The wave ran as long as its longest lane: the maximum of the lanes' own counts.
@@ -1040,7 +1119,7 @@ void trace_kernel(const TraceParams P,
     if (STATS) {
         // Sum over the wave with cross-lane shuffles, one atomic per wave and counter.
         uint32_t c[ST_COUNT] = { n_samples, n_segments, n_diffuse, n_specular, n_terminal, n_tri, n_node, (lane == 0u) ? n_iterations : 0u,
-                                 (tid == 0u && (q & 3u) == 0u) ? 1u : 0u, n_box_test, n_box_bound };
+                                 (lane == 0u && (q & 3u) == 0u) ? 1u : 0u, n_box_test, n_box_bound };
 #pragma unroll
         for (int k = 0; k < ST_COUNT; ++k) {
             unsigned long long v = c[k];
@@ -1249,14 +1328,17 @@ hipError_t launch_tile_plan(hipStream_t stream, uint32_t* cost, uint32_t* work, 
     return hipGetLastError();
 }
 
-hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams& P, const void* blob,
+hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams& Pin, const void* blob,
                         uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm,
                         const uint32_t* tile_order, uint32_t* tile_cost, uint32_t n_workgroups)
 {
-    const dim3 grid(n_workgroups * (4u / P.group_waves));
     const float4* b = static_cast<const float4*>(blob);
-    const int tri_mode = P.scene.n_tris == 0 ? (P.scene.n_box != 0 ? 1 : 0) : (P.scene.tri_in_lds ? 1 : 2);
-    const size_t lds_bytes = ((size_t)P.scene.lds_words + (tri_mode == 2 ? LDS_WAVE_WORDS_PER_GROUP_GLOBAL : tri_mode ? LDS_WAVE_WORDS_PER_GROUP : 0u)) * 16u;
+    const int tri_mode = Pin.scene.n_tris == 0 ? (Pin.scene.n_box != 0 ? 1 : 0) : (Pin.scene.tri_in_lds ? 1 : 2);
+    TraceParams P = Pin;
+    if (tri_mode == 0 && P.group_waves > 4u) P.group_waves = 4u;          // instances without queues are built for 256 threads
+    P.plan_entries = n_workgroups;
+    const dim3 grid((4u * n_workgroups + P.group_waves - 1u) / P.group_waves);
+    const size_t lds_bytes = ((size_t)P.scene.lds_words + (tri_mode ? lds_wave_words(P.group_waves, tri_mode == 2) : 0u)) * 16u;
     const int geo = tri_mode | (((sem == 0 && P.scene.n_cube != 0) || P.scene.has_glass || P.scene.tcol_off != 0) ? 4 : 0) | (P.rng_mode ? 8 : 0);
 #define RT_CASE(S, G, M) if (sem == S && geo == G && mode == M) return launch_one<S, G, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm, tile_order, tile_cost)
 #define RT_CASES(S, G) RT_CASE(S, G, 0); RT_CASE(S, G, 1); RT_CASE(S, G, 2)

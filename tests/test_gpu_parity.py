@@ -490,10 +490,10 @@ def test_many_boxes_fill_more_than_one_pass(rta, orc):
     assert st["box_tests"] == st["segments"] * 44 and st["box_tests_done"] < st["box_tests"] // 2
 
 
-def test_small_mesh_left_in_global_memory(rta, orc, monkeypatch):
-    """The 292-triangle mesh read from global memory (RT_MESH_IN_GLOBAL, read at upload) instead of staged: the path of a
-    mesh that does not fit, with tree nodes of every level queued."""
-    monkeypatch.setenv("RT_MESH_IN_GLOBAL", "1")
+def test_small_mesh_staged_in_lds(rta, orc, monkeypatch):
+    """The 292-triangle mesh and its tree copied into LDS by every workgroup (RT_MESH_IN_LDS, read at upload) instead of
+    read from global memory as by default: only its level-1 nodes are queued there."""
+    monkeypatch.setenv("RT_MESH_IN_LDS", "1")
     check_config(rta, orc, rta.scenes.config3(width=96, height=54, spp=4, max_depth=8))
 
 

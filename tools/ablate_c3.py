@@ -17,7 +17,10 @@ def run(name, shapes, tris):
         rt.resolve(cfg.width, cfg.height)       # waits
         ts.append(time.perf_counter() - t0)
     st = rt.render(cfg.width, cfg.height, 8, cfg.max_depth, cfg.seed, stats=True)
-    print(f"{name:28s} {min(ts)*1e3:7.2f} ms (incl. ~2.1 ms copy)   segments/sample {st['segments']/st['samples']:.3f}")
+    wi = max(1, st["wave_iterations"])
+    print(f"{name:28s} {min(ts)*1e3:7.2f} ms (incl. ~2.1 ms copy)   segments/sample {st['segments']/st['samples']:.3f}  lane use {st['segments']/(64*wi):.3f}  "
+          f"per wave iteration (lane tests): box bounds {st['box_bound_tests_done']/wi:.1f}, box tests {st['box_tests_done']/wi:.1f}, "
+          f"tree bounds {st['bound_tests_done']/wi:.1f}, triangle tests {st['triangle_tests_done']/wi:.1f}", flush=True)
     rt.close()
 is_box = base.shapes["type"] == 1
 run("full", base.shapes, base.triangles)
