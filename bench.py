@@ -3,9 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one full frame of the workload: clear the accumulator, trace `spp` samples per pixel, sum the
-ranks' accumulators (RCCL) when N > 1, resolve on rank 0.  With N > 1 consecutive frames use two
-accumulators in turn, so that one frame's exchange runs beside the next frame's trace.  The scene and camera are resident in HBM
+A step is one full frame of the workload: clear the accumulator, trace `spp` samples per pixel, exchange the
+ranks' accumulators (RCCL) when N > 1, resolve on rank 0.  Consecutive frames use two accumulators in turn: on one
+GPU each has its own stream, so that one launch's ramp and tail are filled by the next frame's; with N > 1 one
+frame's exchange runs beside the next frame's trace.  The launch duration quoted under "roofline" is measured
+separately with one frame in flight.  The scene and camera are resident in HBM
 before the timed region.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
 traces its own `spp` samples of every pixel (disjoint sample ranges -> weak scaling: the frame gains
 N x spp samples per pixel), or, with --shard rows, its own interleaved bands of rows.
@@ -134,7 +136,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "c5e"])
     ap.add_argument("--shard", default="samples", choices=["samples", "rows"])
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel per rank")
     ap.add_argument("--width", type=int, default=0, help="override the frame width (experiments)")
@@ -142,6 +144,7 @@ def main():
     ap.add_argument("--semantics", type=int, default=-1, choices=[-1, 0, 1], help="override the rule set (experiments): 0 CPU tracer, 1 shader")
     ap.add_argument("--mesh", default="", help="c3 only: the mesh file under ray_tracing_amd/data (default Bunny-LowPoly.off; bunny.off has 4 968 triangles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, help="one GPU: frames in flight, each on its own context and stream (1: one after the other)")
     args = ap.parse_args()
 
     import torch
@@ -183,101 +186,125 @@ def main():
         cfg.spp = args.spp
     if args.semantics >= 0:
         cfg.semantics = args.semantics
-    shard = parallel.plan(args.shard, rank, world, cfg.spp)
-    # With several GPUs consecutive frames alternate between two accumulators (and two contexts bound to
-    # them), so that the framebuffer exchange of frame k runs beside the trace of frame k+1.
-    n_buf = 2 if world > 1 else 1
-    rts, accums = [], []
-    for _ in range(n_buf):
-        rt = rta.scenes.make_renderer(cfg, device=local_rank)
-        rt.setStream(torch.cuda.current_stream().cuda_stream)
-        parallel.apply(rt, shard)
-        accum = torch.zeros(cfg.height, cfg.width, 4, dtype=torch.int32, device="cuda")
-        rt.bindAccum(accum.data_ptr(), cfg.width, cfg.height)
-        rts.append(rt); accums.append(accum)
-    out = torch.empty(cfg.height, cfg.width, 4, dtype=torch.float32, device="cuda")
+    # Frames in flight.  One GPU: consecutive frames alternate between --streams contexts, each with its own
+    # accumulator and HIP stream, so that the ramp and tail of one frame's launch are filled by the next frame's
+    # (a progressive renderer queues its frames the same way).  Several GPUs: two accumulators on one stream, so that
+    # the framebuffer exchange of frame k runs beside the trace of frame k+1.
+    n_buf = max(1, args.streams) if world == 1 else 2
+    streams = [torch.cuda.Stream() for _ in range(n_buf)] if world == 1 else [torch.cuda.current_stream()] * n_buf
 
-    def trace(k, ev=None):
-        rt = rts[k % n_buf]
-        rt.resetAccum()                       # hipMemsetAsync of the bound accumulator on the stream
-        if ev:
-            ev[0].record()
-        rt.render(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, first_sample=shard.first_sample)
-        if ev:
-            ev[1].record()
-        return k, parallel.reduce_framebuffer(accums[k % n_buf], cfg.semantics, async_op=True)
+    def measure(mode):
+        """-> timings and counters of args.steps frames split over the ranks by `mode`."""
+        shard = parallel.plan(mode, rank, world, cfg.spp)
+        rts, accums, outs = [], [], []
+        for i in range(n_buf):
+            rt = rta.scenes.make_renderer(cfg, device=local_rank)
+            rt.setStream(streams[i].cuda_stream)
+            parallel.apply(rt, shard)
+            accum = torch.zeros(cfg.height, cfg.width, 4, dtype=torch.int32, device="cuda")
+            rt.bindAccum(accum.data_ptr(), cfg.width, cfg.height)
+            rts.append(rt); accums.append(accum)
+            outs.append(torch.empty(cfg.height, cfg.width, 4, dtype=torch.float32, device="cuda"))
+        torch.cuda.synchronize()
 
-    def finish(pending):
-        k, work = pending
-        if work is not None:
-            work.wait()                       # the current stream waits for the collective
-        if rank == 0:
+        def trace(k, ev=None):
             rt = rts[k % n_buf]
-            rt.setAccumSamples(parallel.total_samples(shard))
-            rt.resolveDevice(out.data_ptr(), gamma_sqrt=(cfg.semantics == rta.SEM_CPU), flip_rows=True)
+            rt.resetAccum()                       # hipMemsetAsync of the bound accumulator on the context's stream
+            if ev:
+                ev[0].record(streams[k % n_buf])
+            rt.render(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, first_sample=shard.first_sample)
+            if ev:
+                ev[1].record(streams[k % n_buf])
+            return k, parallel.exchange_framebuffer(accums[k % n_buf], cfg.semantics, shard, async_op=True)
 
-    def run(n, events=None):
-        pending = None
-        for k in range(n):
-            nxt = trace(k, events[k] if events else None)
-            say("frame", k, "queued")
+        def finish(pending):
+            k, work = pending
+            if work is not None:
+                work.wait()                       # the current stream waits for the collective
+            if rank == 0:
+                rt = rts[k % n_buf]
+                rt.setAccumSamples(parallel.total_samples(shard))
+                rt.resolveDevice(outs[k % n_buf].data_ptr(), gamma_sqrt=(cfg.semantics == rta.SEM_CPU), flip_rows=True)
+
+        def run(n, events=None, one_context=False):
+            pending = None
+            for k in range(n):
+                nxt = trace(0 if one_context else k, events[k] if events else None)
+                if pending is not None:
+                    finish(pending)               # frame k-1: after frame k's trace is queued
+                if world == 1:
+                    finish(nxt); nxt = None
+                pending = nxt
             if pending is not None:
-                finish(pending)               # frame k-1: after frame k's trace is queued
-                say("frame", k - 1, "finished")
-            if n_buf == 1:
-                finish(nxt); nxt = None
-            pending = nxt
-        if pending is not None:
-            finish(pending)
+                finish(pending)
 
-    # Work counters of one launch (same inputs every step -> same counts); not timed.
-    rts[0].resetAccum()
-    stats = rts[0].render(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, first_sample=shard.first_sample, stats=True)
-
-    say("stats launch done")
-    # A one-shot call: a fresh context (no plan learned from an earlier frame), one render of the whole workload,
-    # waited for.  The process has run the kernel before (the stats launch), so its code is loaded.
-    cold_ms = None
-    if world == 1:
-        rt_cold = rta.scenes.make_renderer(cfg, device=local_rank)
-        rt_cold.setStream(torch.cuda.current_stream().cuda_stream)
-        accums[0].zero_()
-        rt_cold.bindAccum(accums[0].data_ptr(), cfg.width, cfg.height)
+        # Work counters of one launch (same inputs every step -> same counts); not timed.
+        rts[0].resetAccum()
+        stats = rts[0].render(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, first_sample=shard.first_sample, stats=True)
+        say(mode, "stats launch done")
+        # A one-shot call: a fresh context (no plan learned from an earlier frame), one render of the whole workload,
+        # waited for.  The process has run the kernel before (the stats launch), so its code is loaded.
+        cold_ms = None
+        if world == 1:
+            rt_cold = rta.scenes.make_renderer(cfg, device=local_rank)
+            rt_cold.setStream(streams[0].cuda_stream)
+            accums[0].zero_()
+            rt_cold.bindAccum(accums[0].data_ptr(), cfg.width, cfg.height)
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            rt_cold.render(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, first_sample=shard.first_sample)
+            torch.cuda.synchronize()
+            cold_ms = (time.perf_counter() - tc) * 1e3
+            rt_cold.bindAccum(None, 0, 0)
+            rt_cold.close()
+        run(args.warmup)
+        say(mode, "warmup done")
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
-        tc = time.perf_counter()
-        rt_cold.render(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, first_sample=shard.first_sample)
+        t0 = time.perf_counter()
+        run(args.steps)
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
-        cold_ms = (time.perf_counter() - tc) * 1e3
-        rt_cold.bindAccum(None, 0, 0)
-        rt_cold.close()
-    run(args.warmup)
-    say("warmup done")
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    say("timed region starts")
-    t0 = time.perf_counter()
-    run(args.steps, events)
-    say("timed steps queued")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    say("timed steps done")
-    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
+        elapsed = time.perf_counter() - t0
+        say(mode, "timed steps done")
+        # The dominant kernel's launch duration, from HIP events on the stream it is launched on: the same K frames
+        # once more, one frame in flight (with two in flight a launch shares the machine and its own duration says
+        # nothing), outside the timed region.
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        run(args.steps, events, one_context=(world == 1))
+        torch.cuda.synchronize()
+        kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        samples = torch.tensor([stats["samples"]], dtype=torch.int64, device="cuda")
+        if world > 1:
+            dist.all_reduce(samples)
+        m = {"shard": shard, "stats": stats, "elapsed": float(t.item()), "samples_per_step": int(samples.item()),
+             "kernel_ms": kernel_ms, "cold_ms": cold_ms, "rts": rts, "accums": accums}
+        return m
 
-    samples_per_step_rank = stats["samples"]
-    samples_per_step = samples_per_step_rank
+    def release(m):
+        for rt in m["rts"]:
+            rt.bindAccum(None, 0, 0)
+            rt.close()
+
+    # With several GPUs both splits are measured: the headline line is --shard's, the other one rides along.
+    other = None
     if world > 1:
-        s = torch.tensor([samples_per_step_rank], dtype=torch.int64, device="cuda")
-        dist.all_reduce(s)
-        samples_per_step = int(s.item())
+        other_mode = "rows" if args.shard == "samples" else "samples"
+        mo = measure(other_mode)
+        other = {"shard": other_mode, "scaling": "weak" if other_mode == "samples" else "strong",
+                 "value": round(mo["samples_per_step"] / (mo["elapsed"] / args.steps) / 1e6, 2), "unit": "Msamples/s",
+                 "ms_per_step": round(mo["elapsed"] / args.steps * 1e3, 4), "kernel_ms": round(mo["kernel_ms"], 4),
+                 "exchange_bytes_per_rank": parallel.exchange_bytes(other_mode, cfg.width, cfg.height, world)}
+        release(mo)
+    m = measure(args.shard)
+    shard, stats, elapsed, samples_per_step, kernel_ms, cold_ms = m["shard"], m["stats"], m["elapsed"], m["samples_per_step"], m["kernel_ms"], m["cold_ms"]
+    rts, accums = m["rts"], m["accums"]
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -317,7 +344,9 @@ def main():
             "config": {"workload": f"{cfg.name}: {cfg.width}x{cfg.height}, {shard.spp} spp per GPU, depth {cfg.max_depth}, "
                                    f"{len(cfg.shapes)} shapes + {len(cfg.triangles)} triangles, "
                                    f"{'cpu_version' if cfg.semantics == rta.SEM_CPU else 'RayTracing.glsl'} semantics, seed {cfg.seed}",
-                       "shard": args.shard, "spp_total": parallel.total_samples(shard), "device": info["name"]},
+                       "shard": args.shard, "spp_total": parallel.total_samples(shard), "device": info["name"],
+                       "frames_in_flight": n_buf,
+                       "exchange_bytes_per_rank": parallel.exchange_bytes(args.shard, cfg.width, cfg.height, world)},
             "mrays_per_s": round(stats["segments"] * world / (elapsed / args.steps) / 1e6, 2),
             "segments_per_sample": round(stats["segments"] / max(1, stats["samples"]), 4),
             # share of the lane-iterations of the bounce loop that traced a segment (the rest: lanes whose pixel had
@@ -333,6 +362,8 @@ def main():
                          "valu_issue": issue,
                          "note": "fp32 vector (VALU) bound: no dense contraction, no MFMA; HBM traffic is the framebuffer only"},
         }
+        if other is not None:
+            result["other_split"] = other
         if world == 1 and not args.no_cpu_baseline:
             def gpu_render(spp):
                 rt = rts[0]
@@ -343,9 +374,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(cfg, gpu_render=gpu_render)
         print(json.dumps(result), flush=True)
 
-    for rt in rts:
-        rt.bindAccum(None, 0, 0)
-        rt.close()
+    release(m)
     if world > 1:
         dist.destroy_process_group()
 

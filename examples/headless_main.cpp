@@ -21,10 +21,12 @@ static bool writePFM(const std::string& path, const std::vector<float>& rgba, un
 {
     FILE* f = std::fopen(path.c_str(), "wb");
     if (!f) return false;
-    std::fprintf(f, "PF\n%u %u\n-1.0\n", width, height);          // little-endian, rows bottom to top
+    // little-endian; a PFM file holds its scanlines bottom to top, and so does the image read back from the
+    // library (row 0 is the bottom of the view, the order of the reference's texture): rows go out in index order
+    std::fprintf(f, "PF\n%u %u\n-1.0\n", width, height);
     std::vector<float> row(3 * (size_t)width);
     for (unsigned int y = 0; y < height; ++y) {
-        const float* src = &rgba[4 * (size_t)(height - 1 - y) * width];
+        const float* src = &rgba[4 * (size_t)y * width];
         for (unsigned int x = 0; x < width; ++x) { row[3 * x] = src[4 * x]; row[3 * x + 1] = src[4 * x + 1]; row[3 * x + 2] = src[4 * x + 2]; }
         std::fwrite(row.data(), sizeof(float), row.size(), f);
     }

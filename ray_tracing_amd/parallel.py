@@ -5,17 +5,20 @@ Every sample of every pixel is independent and its random stream depends only
 on (seed, pixel, sample), so a frame can be cut two ways:
 
 * rows    — rank r renders the rows y with (y // band) % world == r.  The
-            accumulators of the ranks are disjoint, so their element-wise sum
-            is bit-identical to a single-GPU render.
+            accumulators of the ranks are disjoint, so the assembled frame is
+            bit-identical to a single-GPU render.  The exchange is a GATHER
+            of each rank's own bands to rank 0: width*height*16/world bytes
+            per rank on the wire.
 * samples — rank r renders samples [r*spp, (r+1)*spp) of every pixel; the sum
             of the accumulators is a frame of world*spp samples per pixel.
+            The exchange is ONE sum-reduce of the accumulator to rank 0
+            (width*height*16 bytes through every rank of the ring).
 
-Both end in the same exchange: ONE sum-reduce of the accumulator to rank 0
-(`torch.distributed.reduce`, RCCL on GPUs, gloo on CPU), followed by the
-resolve on rank 0.  With float accumulators (CPU-tracer semantics) the sample
-split changes the order of the float additions, so it matches a single-GPU
-render to rounding, not bitwise; with the shader semantics' integer
-accumulators it is exact either way.
+Either way the exchange is a single collective (`torch.distributed`, RCCL on
+GPUs, gloo on CPU) followed by the resolve on rank 0.  With float accumulators
+(CPU-tracer semantics) the sample split changes the order of the float
+additions, so it matches a single-GPU render to rounding, not bitwise; with
+the shader semantics' integer accumulators it is exact either way.
 """
 from dataclasses import dataclass
 
@@ -53,7 +56,7 @@ def apply(renderer, shard):
 
 
 def total_samples(shard):
-    """Samples per pixel in the reduced frame."""
+    """Samples per pixel in the exchanged frame."""
     return shard.spp if shard.mode == "rows" else shard.spp * shard.world
 
 
@@ -62,16 +65,85 @@ def accum_view(accum_words, semantics):
     return accum_words.view(torch.float32) if semantics == SEM_CPU else accum_words
 
 
-def reduce_framebuffer(accum_words, semantics, dst=0, group=None, async_op=False):
-    """Sum the ranks' accumulators into rank `dst` (in place there).
+def owned_rows(height, rank, world, band_rows):
+    """Image rows of rank `rank`: y with (y // band_rows) % world == rank (rt_set_row_shard's rule), ascending."""
+    y = torch.arange(height)
+    return y[(y // band_rows) % world == rank]
+
+
+def exchange_bytes(mode, width, height, world):
+    """Bytes each rank puts on the wire for one frame (for predictions; the frame has 16 bytes per pixel)."""
+    frame = width * height * 16
+    if world <= 1:
+        return 0
+    # ring reduce: every rank forwards (world - 1) / world of the frame; band gather: a rank sends its own bands once
+    return frame * (world - 1) // world if mode == "samples" else frame // world
+
+
+def reduce_framebuffer(accum_words, semantics, dst=0, group=None, async_op=False, always=False):
+    """Sum the ranks' accumulators into rank `dst` (in place there): the exchange of the `samples` split.
 
     With async_op the collective is only queued (behind the work already on the current stream) and
     its handle returned: the caller can launch the next frame's trace before calling .wait(), so
-    that the exchange over xGMI runs beside it."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    that the exchange over xGMI runs beside it.  A single-rank group returns None without a
+    collective unless `always` is set (tests run the RCCL call itself that way)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always):
         return None
     t = accum_view(accum_words, semantics)
     if t.is_cuda and dist.get_backend(group) == "gloo":
         # gloo has no reduce for device tensors; its all_reduce gives rank `dst` the same sum (rehearsals only)
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     return dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+class _BandGather:
+    """Handle of a queued band gather: .wait() completes it and, on the destination, puts the bands in place."""
+
+    def __init__(self, work, place):
+        self._work, self._place = work, place
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+        if self._place is not None:
+            self._place()
+            self._place = None
+        return True
+
+
+def gather_bands(accum_words, shard, dst=0, group=None, async_op=False, always=False):
+    """The exchange of the `rows` split: every rank sends the bands it rendered to rank `dst`, which puts them into
+    its own accumulator (in place).  A rank's bands are copied into one contiguous send buffer (padded to the
+    largest rank's row count, so that all contributions have one size), one gather moves them, and `dst` writes
+    rank r's rows back with the same row index list.  Nothing is summed: the frame is bit-identical to a single-GPU
+    render whatever the sums' type."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always):
+        return None
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    height = accum_words.shape[0]
+    rows = [owned_rows(height, r, world, shard.band_rows).to(accum_words.device) for r in range(world)]
+    most = max(len(r) for r in rows)
+    send = accum_words.new_zeros((most,) + tuple(accum_words.shape[1:]))
+    send[:len(rows[rank])] = accum_words.index_select(0, rows[rank])
+    on_host = accum_words.is_cuda and dist.get_backend(group) == "gloo"      # rehearsals: gloo gathers host tensors only
+    buf = send.cpu() if on_host else send
+    recv = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    work = dist.gather(buf, recv, dst=dst, group=group, async_op=async_op)
+
+    def place():
+        for r in range(world):
+            if r != dst:
+                accum_words.index_copy_(0, rows[r], recv[r][:len(rows[r])].to(accum_words.device))
+
+    handle = _BandGather(work if async_op else None, place if rank == dst else None)
+    if async_op:
+        return handle
+    handle.wait()
+    return None
+
+
+def exchange_framebuffer(accum_words, semantics, shard, dst=0, group=None, async_op=False, always=False):
+    """The one exchange of a frame: a band gather for the `rows` split, a sum-reduce for the `samples` split."""
+    if shard.mode == "rows":
+        return gather_bands(accum_words, shard, dst=dst, group=group, async_op=async_op, always=always)
+    return reduce_framebuffer(accum_words, semantics, dst=dst, group=group, async_op=async_op, always=always)

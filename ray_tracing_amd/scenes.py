@@ -138,9 +138,7 @@ def config4(width=3840, height=2160, spp=1024, max_depth=11):
                        width, height, spp, max_depth, SEM_CPU)
 
 
-def config5(width=2048, height=2048, spp=64, max_depth=16):
-    """Divergence stress (not in the reference): 64 spheres on a jittered 8x8
-    grid, materials round-robin diffuse / mirror / fuzzy metal / glass / light."""
+def _config5_objects():
     rng = np.random.RandomState(7)
     L, M, Li, G = host.Lambertian, host.Metal, host.Light, host.Dielectric
     objs = [host.Circle((0, -1000.5, -6), 1000, L((0.5, 0.5, 0.5)))]
@@ -163,7 +161,32 @@ def config5(width=2048, height=2048, spp=64, max_depth=16):
                 m = Li(tuple(3.0 * c for c in col))
             objs.append(host.Circle(pos, 0.4, m))
             k += 1
-    return SceneConfig("c5_divergence", _shapes(objs), np.zeros(0, TRIANGLE_DTYPE),
+    return objs
+
+
+def config5(width=2048, height=2048, spp=64, max_depth=16):
+    """Divergence stress (not in the reference): 64 spheres on a jittered 8x8
+    grid, materials round-robin diffuse / mirror / fuzzy metal / glass / light."""
+    return SceneConfig("c5_divergence", _shapes(_config5_objects()), np.zeros(0, TRIANGLE_DTYPE),
+                       _camera(width, height, (1, 1.5, 6)), width, height, spp, max_depth, SEM_CPU)
+
+
+def config5_enclosed(width=2048, height=2048, spp=64, max_depth=16):
+    """Config 5's spheres inside a room, so that a path ends only on one of the eleven light spheres or at its
+    sixteenth segment: long paths, lanes of a wave at very different depths.  The walls are the shader's Boxes
+    (cubes of side 200 seen from outside, RayTracing.glsl:138-156: a Box is hit on the faces of the octant its
+    origin lies in, so a room is five cubes around it, not one cube entered from inside): left and back diffuse,
+    right a mirror, front (behind the camera) and ceiling diffuse; the floor is config 5's ground sphere."""
+    L, M = host.Lambertian, host.Metal
+    s = 200.0
+    walls = [
+        host.Box((-5.0 - s / 2, 0, 0), (s, s, s), L((0.75, 0.25, 0.25))),      # left,    x = -5
+        host.Box((7.0 + s / 2, 0, 0), (s, s, s), M((0.9, 0.9, 0.9))),          # right,   x =  7: mirror
+        host.Box((0, 0, -12.0 - s / 2), (s, s, s), L((0.25, 0.25, 0.75))),     # back,    z = -12
+        host.Box((0, 0, 8.0 + s / 2), (s, s, s), L((0.7, 0.7, 0.7))),          # front,   z =  8
+        host.Box((0, 5.0 + s / 2, 0), (s, s, s), L((0.7, 0.7, 0.7))),          # ceiling, y =  5
+    ]
+    return SceneConfig("c5_enclosed", _shapes(_config5_objects() + walls), np.zeros(0, TRIANGLE_DTYPE),
                        _camera(width, height, (1, 1.5, 6)), width, height, spp, max_depth, SEM_CPU)
 
 
@@ -212,7 +235,7 @@ def config_box_sides(width=320, height=200, spp=16, max_depth=6, semantics=SEM_G
                        width, height, spp, max_depth, semantics, flags=_abi.FLAG_BOX_SIDES)
 
 
-CONFIGS = {"colored_mesh": config_colored_mesh, "box_sides": config_box_sides, "cpu_tracer": config_cpu_tracer, "c1": config1, "c2": config2, "c3": config3, "c4": config4, "c5": config5}
+CONFIGS = {"colored_mesh": config_colored_mesh, "box_sides": config_box_sides, "cpu_tracer": config_cpu_tracer, "c1": config1, "c2": config2, "c3": config3, "c4": config4, "c5": config5, "c5e": config5_enclosed}
 
 
 def make_renderer(cfg, device=0):

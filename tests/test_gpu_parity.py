@@ -78,6 +78,12 @@ def test_config5_divergence_scene(rta, orc):
     check_config(rta, orc, rta.scenes.config5(width=128, height=128, spp=8, max_depth=16), trace_samples=(3,))
 
 
+def test_config5_enclosed_room(rta, orc):
+    """Config 5's spheres inside five wall boxes: paths of ten and more segments, CPU rules with boxes, metal walls."""
+    st = check_config(rta, orc, rta.scenes.config5_enclosed(width=96, height=96, spp=6, max_depth=16), trace_samples=(2,))
+    assert st["segments"] >= 5 * st["samples"]
+
+
 def test_cpu_tracer_scene_as_shipped(rta, orc):
     """rayTracer.h:48-61 in full — spheres, fuzzy metal and the rotated Cube (scene.h:142-217) — on the 5 x 5 grid
     of renderPixel<5> as written, 11 segments."""
@@ -228,30 +234,50 @@ def test_first_frame_of_a_fresh_context_equals_the_oracle(rta, orc):
         rt.close()
 
 
-def test_full_size_properties(rta):
-    """Config 2 at full size (1920x1080, 100 spp, depth 8): properties that need no oracle run."""
-    cfg = rta.scenes.config2()
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
+def test_full_size_properties(rta, name, monkeypatch):
+    """Configurations 2-5 at their full sizes: properties that need no oracle run (counters, idempotence, linearity in
+    the sample split, seed independence of the mean; for the mesh scene also: the frame does not depend on the launch
+    plan — tile order, slices of the sample range — or on where the mesh lives)."""
+    cfg = rta.scenes.CONFIGS[name]()
+    w, h, spp = cfg.width, cfg.height, cfg.spp
     rt = rta.scenes.make_renderer(cfg)
-    st = rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, stats=True)
-    img = rt.resolve(cfg.width, cfg.height)
-    assert st["samples"] == 1920 * 1080 * 100 and st["terminal"] == st["samples"]
-    assert st["samples"] <= st["segments"] <= 8 * st["samples"]
-    assert np.isfinite(img).all() and img[..., :3].min() >= 0 and img[..., :3].max() <= 5.0
-    # idempotence: the same call again gives the same words
+    st = rt.render(w, h, spp, cfg.max_depth, cfg.seed, stats=True)
+    img = rt.resolve(w, h)
+    assert st["samples"] == w * h * spp and st["terminal"] == st["samples"]
+    assert st["samples"] <= st["segments"] <= cfg.max_depth * st["samples"]
+    assert st["segments"] - st["terminal"] <= st["diffuse"] + st["specular"] <= st["segments"]     # every segment that went on scattered
+    assert st["shape_tests"] == st["segments"] * len(cfg.shapes) and st["triangle_tests"] == st["segments"] * len(cfg.triangles)
+    assert st["triangle_tests_done"] <= st["triangle_tests"] and st["box_tests_done"] <= st["box_tests"]
+    assert np.isfinite(img).all() and img[..., :3].min() >= 0 and img[..., :3].max() <= 10.0
+    words = img.view(np.uint32)
+    # idempotence: the same call again (now by the plan made from the first frame) gives the same words
     rt.resetAccum()
-    rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed)
-    np.testing.assert_array_equal(rt.resolve(cfg.width, cfg.height).view(np.uint32), img.view(np.uint32))
-    # linearity in the sample split: 60 + 40 samples == 100
+    rt.render(w, h, spp, cfg.max_depth, cfg.seed)
+    np.testing.assert_array_equal(rt.resolve(w, h).view(np.uint32), words)
+    # linearity in the sample split: 60 % + 40 % of the samples == all of them
+    first = spp * 6 // 10
     rt.resetAccum()
-    rt.render(cfg.width, cfg.height, 60, cfg.max_depth, cfg.seed, first_sample=0)
-    rt.render(cfg.width, cfg.height, 40, cfg.max_depth, cfg.seed, first_sample=60)
-    np.testing.assert_array_equal(rt.resolve(cfg.width, cfg.height).view(np.uint32), img.view(np.uint32))
+    rt.render(w, h, first, cfg.max_depth, cfg.seed, first_sample=0)
+    rt.render(w, h, spp - first, cfg.max_depth, cfg.seed, first_sample=first)
+    np.testing.assert_array_equal(rt.resolve(w, h).view(np.uint32), words)
     # a different seed gives a different image with the same mean to Monte-Carlo accuracy
     rt.resetAccum()
-    rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed + 1)
-    img2 = rt.resolve(cfg.width, cfg.height)
+    rt.render(w, h, spp, cfg.max_depth, cfg.seed + 1)
+    img2 = rt.resolve(w, h)
     assert (img2 != img).any() and abs(img2[..., :3].mean() - img[..., :3].mean()) < 0.01 * img[..., :3].mean()
     rt.close()
+    if name == "c3":
+        # fresh contexts: no plan at all (built-in tile order, no slices), and the mesh staged in LDS
+        for env in ({"RT_NO_TILE_ORDER": "1"}, {"RT_MESH_IN_LDS": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            rt = rta.scenes.make_renderer(cfg)
+            rt.render(w, h, spp, cfg.max_depth, cfg.seed)
+            np.testing.assert_array_equal(rt.resolve(w, h).view(np.uint32), words)
+            rt.close()
+            for k in env:
+                monkeypatch.delenv(k)
 
 
 def test_argument_errors(rta):
@@ -298,9 +324,11 @@ def test_headless_cpp_driver_matches_python_host(rta, tmp_path):
     rt = rta.scenes.make_renderer(cfg)
     for n in (1, 2):
         rt.updateCameraBuffer(); rt.compute(96, 54, 1); rt.convert(n)
-    want = rt.readImage()[..., :3]
+    want = rt.readImage()[::-1, :, :3]           # the library's image has the bottom of the view in row 0; a PFM reader returns the top first
     rt.close()
     np.testing.assert_array_equal(got.view(np.uint32), np.ascontiguousarray(want).view(np.uint32))
+    # orientation as a PFM reader sees it: the lit floor at the bottom of the picture, the black sky at the top
+    assert got.shape == (54, 96, 3) and got[-8:].mean() > 0.05 and got[:8].mean() < 0.01
 
 
 @pytest.mark.parametrize("sem", [0, 1])
@@ -530,3 +558,90 @@ def test_random_scenes(rta, orc, seed):
                                  host.Camera(w, h, 1.0, (1, 1, 6)).data.copy(), w, h, 3, 5, sem, seed=seed + 1)
     check_config(rta, orc, cfg, trace_samples=(0, 2))
 
+
+
+def test_rccl_exchanges_on_one_rank(rta):
+    """The RCCL branch of both exchanges on hardware: a one-rank `nccl` group (a node is not ours to use), the collective
+    forced although one rank has nothing to exchange; integer and float views, the async handle, two accumulators in turn
+    as bench.py uses them, and the band gather of the `rows` split."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from ray_tracing_amd import parallel
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for sem in (rta.SEM_GLSL, rta.SEM_CPU):
+            cfg = rta.scenes.config2(width=320, height=176, spp=4, max_depth=4)
+            cfg.semantics = sem
+            shard = parallel.plan("samples", 0, 1, cfg.spp)
+            rts, accums = [], []
+            for _ in range(2):
+                rt = rta.scenes.make_renderer(cfg)
+                rt.setStream(torch.cuda.current_stream().cuda_stream)
+                acc = torch.zeros(cfg.height, cfg.width, 4, dtype=torch.int32, device="cuda")
+                rt.bindAccum(acc.data_ptr(), cfg.width, cfg.height)
+                rts.append(rt); accums.append(acc)
+            pending, frames = None, []
+            for k in range(4):                                   # frame k's exchange is waited for after frame k+1's trace is queued
+                rt = rts[k % 2]
+                rt.resetAccum()
+                rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed + k)
+                work = parallel.reduce_framebuffer(accums[k % 2], sem, async_op=True, always=True)
+                assert work is not None
+                if pending is not None:
+                    pending[1].wait()
+                    frames.append(accums[pending[0] % 2].cpu().numpy().copy())
+                pending = (k, work)
+            pending[1].wait()
+            frames.append(accums[pending[0] % 2].cpu().numpy().copy())
+            # a sum over one rank changes nothing: every frame equals the same render without an exchange
+            ref = rta.scenes.make_renderer(cfg)
+            racc = torch.zeros(cfg.height, cfg.width, 4, dtype=torch.int32, device="cuda")
+            ref.setStream(torch.cuda.current_stream().cuda_stream)
+            ref.bindAccum(racc.data_ptr(), cfg.width, cfg.height)
+            for k in range(4):
+                ref.resetAccum()
+                ref.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed + k)
+                torch.cuda.synchronize()
+                np.testing.assert_array_equal(frames[k], racc.cpu().numpy())
+            ref.bindAccum(None, 0, 0)
+            ref.close()
+            # the rows split's gather: the one rank owns every band
+            rshard = parallel.plan("rows", 0, 1, cfg.spp)
+            before = accums[0].clone()
+            handle = parallel.gather_bands(accums[0], rshard, async_op=True, always=True)
+            handle.wait()
+            torch.cuda.synchronize()
+            assert torch.equal(accums[0], before)
+            for rt in rts:
+                rt.bindAccum(None, 0, 0)
+                rt.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("split", ["rows", "samples"])
+def test_cpp_multi_gpu_driver_on_one_gpu(rta, tmp_path, split):
+    """examples/multi_gpu (C++ host, RCCL through its C API: ncclCommInitAll, grouped send / recv of the row bands or one
+    ncclReduce) with a one-GPU communicator == the same frame from one context."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "multi_gpu")
+    assert os.path.exists(exe), "examples/multi_gpu is not built (run __graft_entry__.build())"
+    out = str(tmp_path / "frame.pfm")
+    r = subprocess.run([exe, "--gpus", "1", "--split", split, "--width", "96", "--height", "54", "--spp", "8", "--frames", "2", "--out", out],
+                       check=True, timeout=120, capture_output=True, text=True)
+    assert "1 GPU(s)" in r.stdout
+    got = read_pfm(out)
+    cfg = rta.scenes.config3(width=96, height=54, spp=8, max_depth=10)
+    cfg.triangles = cfg.triangles[:0]
+    rt = rta.scenes.make_renderer(cfg)
+    rt.render(96, 54, 8, 10, 2)                       # the driver's second frame has seed 2
+    want = rt.resolve(96, 54)[::-1, :, :3]
+    rt.close()
+    np.testing.assert_array_equal(got.view(np.uint32), np.ascontiguousarray(want).view(np.uint32))

@@ -1,5 +1,5 @@
 """The N > 1 path on CPU: two gloo ranks shard a frame the way bench.py's GPU ranks do
-(parallel.plan / parallel.reduce_framebuffer), with the CPU oracle standing in for the kernel."""
+(parallel.plan / parallel.exchange_framebuffer), with the CPU oracle standing in for the kernel."""
 import os
 import socket
 import sys
@@ -33,7 +33,7 @@ def _worker(rank, world, port, mode, config, out_path):
                    shard=(shard.rank, shard.world, shard.band_rows) if mode == "rows" else (0, 1, 16), threads=2)
     acc, _ = orc.render(cfg.shapes, cfg.triangles, cfg.camera, p)
     t = torch.from_numpy(acc.view(np.int32).copy())
-    parallel.reduce_framebuffer(t, cfg.semantics)              # one reduce(SUM) to rank 0
+    parallel.exchange_framebuffer(t, cfg.semantics, shard)     # rows: a gather of the owned bands; samples: one reduce(SUM) to rank 0
     if rank == 0:
         np.save(out_path, t.numpy().view(np.uint32))
         assert parallel.total_samples(shard) == (cfg.spp if mode == "rows" else cfg.spp * world)
@@ -68,3 +68,38 @@ def test_plan_covers_every_row_and_sample():
         shards = [parallel.plan("samples", r, world, 100) for r in range(world)]
         covered = sorted(s for sh in shards for s in range(sh.first_sample, sh.first_sample + sh.spp))
         assert covered == list(range(100 * world))
+
+
+def _gather_worker(rank, world, port, height, band, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ray_tracing_amd import parallel
+    shard = parallel.plan("rows", rank, world, 1, band_rows=band)
+    # every rank's frame holds its rank + 1 in its own rows and a poison value elsewhere
+    t = torch.full((height, 5, 4), -7, dtype=torch.int32)
+    t[parallel.owned_rows(height, rank, world, band)] = rank + 1
+    handle = parallel.gather_bands(t, shard, async_op=True)
+    handle.wait()
+    if rank == 0:
+        np.save(out_path, t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,height,band", [(2, 40, 16), (3, 50, 8), (2, 7, 16)])
+def test_band_gather_puts_every_rank_s_rows_in_place(tmp_path, world, height, band):
+    """Ragged cases: a last band that is cut short, ranks with different row counts, a rank without any row."""
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_gather_worker, args=(world, _free_port(), height, band, out), nprocs=world, join=True)
+    got = np.load(out)
+    want = ((np.arange(height) // band) % world + 1).astype(np.int32)
+    np.testing.assert_array_equal(got, np.broadcast_to(want[:, None, None], got.shape))
+
+
+def test_exchange_bytes():
+    from ray_tracing_amd import parallel
+    frame = 1920 * 1080 * 16
+    assert parallel.exchange_bytes("rows", 1920, 1080, 8) == frame // 8
+    assert parallel.exchange_bytes("samples", 1920, 1080, 8) == frame * 7 // 8
+    assert parallel.exchange_bytes("rows", 1920, 1080, 1) == 0
