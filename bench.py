@@ -313,12 +313,13 @@ def main():
         achieved = flops / (kernel_ms * 1e-3) / 1e12
         # Counters of the same launch from the committed rocprofv3 passes (profiles/traffic.json): HBM bytes, and
         # the vector instructions issued, which price the launch in issue slots of the vector pipe.
-        traffic, issue, traffic_note = None, None, None
+        traffic, issue, traffic_note, bound = None, None, None, "valu"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath)).get(f"{args.config}_{cfg.width}x{cfg.height}_{shard.spp}spp", {}) if not args.mesh else {}
                 traffic = tj.get("hbm_bytes_per_launch")
+                bound = tj.get("bound", "valu")               # "lds" where the profile shows the LDS busier than the vector pipe
                 if traffic is not None:
                     traffic_note = {"source": "replayed from " + str(tj.get("source", "profiles/")) + " (rocprofv3 --pmc passes of this "
                                               "command; not measured in this run)",
@@ -330,7 +331,8 @@ def main():
                     issue = {"valu_instructions_per_launch": n_inst, "cycles_per_instruction_per_simd": round(cyc, 3),
                              "best_cycles_per_instruction": 2.0, "issue_slots_used": round(2.0 / cyc, 4),
                              "lanes_enabled_percent": tj.get("valu_lane_utilisation_percent"),
-                             "mean_waves_per_simd": tj.get("mean_waves_per_simd"), "source": tj.get("source"),
+                             "mean_waves_per_simd": tj.get("mean_waves_per_simd"), "lds_busy_percent": tj.get("lds_busy_percent"),
+                             "source": tj.get("source"),
                              "note": "1024 SIMDs at 2.4 GHz; a wave64 fp32 instruction issues in 2 cycles at best, compares / selects / "
                                      "conversions / integer multiplies in 4, sqrt / rcp in 8"}
             except Exception:
@@ -353,7 +355,7 @@ def main():
             # no samples left while their wave went on)
             "lane_use": round(stats["segments"] / max(1, 64 * stats["wave_iterations"]), 4),
             "cold_first_frame_ms": None if cold_ms is None else round(cold_ms, 4),
-            "roofline": {"bound": "valu", "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": bound, "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "trace_kernel", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_flops_per_launch": flops,

@@ -52,6 +52,21 @@ def main():
         d["wave_time_waiting_for_issue_percent"] = round(100.0 * c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 1)
     if "SQ_INSTS_VALU" in c and "SQ_INSTS_SALU" in c:
         d["salu_per_valu_instruction"] = round(c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"], 3)
+    if "SQ_INSTS_VALU_TRANS" in c and "SQ_INSTS_VALU" in c:
+        d["transcendental_share_of_valu_percent"] = round(100.0 * c["SQ_INSTS_VALU_TRANS"] / c["SQ_INSTS_VALU"], 2)
+    if "SQ_LDS_IDX_ACTIVE" in c and "kernel_cycles" in d:
+        # the LDS of a CU is busy while its index unit is: cycles summed over the 256 CUs
+        d["lds_busy_percent"] = round(100.0 * c["SQ_LDS_IDX_ACTIVE"] / (d["kernel_cycles"] * 256.0), 1)
+        if "SQ_LDS_BANK_CONFLICT" in c:
+            d["lds_busy_cycles_lost_to_bank_conflicts_percent"] = round(100.0 * c["SQ_LDS_BANK_CONFLICT"] / max(1.0, c["SQ_LDS_IDX_ACTIVE"]), 1)
+        if "SQ_INSTS_LDS" in c and c.get("SQ_WAVES"):
+            d["lds_instructions_per_wave"] = round(c["SQ_INSTS_LDS"] / c["SQ_WAVES"], 1)
+    if "cycles_per_valu_instruction_per_simd" in d:
+        # what fills the launch: the share of the vector pipe's issue slots in use (2 cycles per instruction at best)
+        # against the share of the time the LDS is busy
+        valu = 2.0 / d["cycles_per_valu_instruction_per_simd"]
+        d["valu_issue_slots_used"] = round(valu, 3)
+        d["bound"] = "lds" if d.get("lds_busy_percent", 0.0) / 100.0 > valu else "valu"
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         d["hbm_bytes_per_launch"] = round((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0)                   # gfx950: FETCH_SIZE tallies 128-B requests at 64 B
     out["derived"] = d
