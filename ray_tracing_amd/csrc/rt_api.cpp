@@ -321,7 +321,7 @@ static int plan_blob(rt_ctx* ctx, BlobPlan& B)
     rtd::SceneLayout L{};
     L.n_shapes = n_shapes; L.n_sph_pad = (n_sph + 3u) & ~3u; L.n_box = n_box; L.n_cube = n_cube; L.n_tris = n_tris;
     L.rec_off = 0;
-    L.sph_off = L.rec_off + 4u * n_shapes;
+    L.sph_off = L.rec_off + 4u * (n_shapes + 1u);          // one record more: what a miss reads
     L.sid_off = L.sph_off + L.n_sph_pad;
     L.box_off = L.sid_off + L.n_sph_pad / 4u;
     // Bounding-sphere tree over the triangles (rt_device.h).
@@ -388,10 +388,22 @@ static int build_blob_impl(rt_ctx* ctx)
             // Lambertian::scatter attenuates by 0.6 * albedo (scene.h:56): formed once here.
             r = r * 0.6f; g = g * 0.6f; b = b * 0.6f;
         }
+        // What the event at this surface is (rt_device.h): class and emission factor.
+        uint32_t cls = 0u; float emit = 0.0f;
+        switch (s.material.type) {
+        case RT_MAT_LIGHT: emit = 1.0f; break;
+        case RT_MAT_LAMBERTIAN: cls = 1u; break;
+        case RT_MAT_METAL: cls = 2u; break;
+        case RT_MAT_DIELECTRIC: cls = 3u; break;
+        case RT_MAT_DEBUG: cls = 4u; L.has_debug = 1; break;
+        default:                                            // glsl:253,282-284 returns the throughput; the CPU tracer has no such material: black
+            if (ctx->cfg.semantics == RT_SEM_GLSL) { emit = 1.0f; r = g = b = 1.0f; }
+            break;
+        }
         r1.f[0] = r; r1.f[1] = g; r1.f[2] = b;
-        as_u32(r1.f[3]) = (s.material.type & 0xffffu) | ((s.type & 0xffffu) << 16);
-        r2.f[0] = s.material.data[1];                     // fuzz
-        r2.f[1] = s.material.data[0];                     // ior
+        as_u32(r1.f[3]) = (s.material.type & 0xffffu) | ((s.type & 0xffu) << 16) | (cls << 24);
+        r2.f[0] = cls == 2u && ctx->cfg.semantics == RT_SEM_CPU ? s.material.data[1] : 0.0f;   // fuzz: the CPU tracer's metal only (scene.h:71,78)
+        r2.f[1] = emit;
         r2.f[2] = rcp_nr(scale);
         // A Box's sides along y and z: the shader's single side, or its own (RT_FLAG_BOX_SIDES).
         const bool own_sides = (ctx->cfg.flags & RT_FLAG_BOX_SIDES) != 0u;

@@ -13,12 +13,16 @@ namespace rtd {
 // mesh and its tree then being read from the blob in global memory with
 // wave-uniform addresses.
 //
-//   rec  [4 * n_shapes]   per shape, by the shape's index in the uploaded array:
+//   rec  [4 * (n_shapes + 1)] per shape, by the shape's index in the uploaded array, and one more for "nothing hit":
 //                           word 0: centre.xyz, scale (Circle: radius, Box: side)
-//                           word 1: colour.rgb (x 0.6 for Lambertian under CPU rules), tag
-//                                   tag = material type | shape type << 16
-//                           word 2: fuzz, ior, rcp_nr(scale), place in cub (uint32; cubes only)
-//                           word 3: dielectric: 1/ior, Schlick's r0 = ((1-ior)/(1+ior))^2
+//                           word 1: colour.rgb (x 0.6 for Lambertian under CPU rules; 1 for a material the shader
+//                                   does not know), tag = material type | shape type << 16 | class << 24
+//                                   class: 0 the path ends here and returns throughput x colour x emit,
+//                                          1 Lambertian, 2 metal, 3 dielectric, 4 debug (returns the normal)
+//                           word 2: fuzz, emit (1: light, or unknown material under the shader's rules; else 0),
+//                                   rcp_nr(scale), place in cub (uint32; cubes only)
+//                           word 3: dielectric: 1/ior, Schlick's r0 = ((1-ior)/(1+ior))^2; box: 1/side y, 1/side z
+//                         the record behind the shapes' is all zero: class 0, emit 0, colour 0
 //   sph  [n_sph_pad]      spheres in upload order: centre.xyz, radius^2; padded to a
 //                         multiple of 4 with NaN centres (never hit)
 //   sid  [n_sph_pad / 4]  the spheres' shape indices, four per word
@@ -51,6 +55,7 @@ struct SceneLayout {
     uint32_t tri_in_lds;                                    // 1 if the tree and tri are part of that prefix
     uint32_t has_glass;                                     // 1 if any shape has the dielectric material
     uint32_t tcol_off;                                      // 0: all triangles share TraceParams::tri_albedo
+    uint32_t has_debug;                                     // 1 if any shape has the debug material
 };
 
 // Everything one trace launch needs besides the blob; passed by value in the

@@ -895,65 +895,66 @@ void trace_kernel(const TraceParams P,
         if (STATS) { ++n_segments; }
 
         // ---- the surface
-        uint32_t type = NONE;                  // nothing hit
-        V3 n = v3(0, 0, 0), att = v3(0, 0, 0);
-        float fuzz = 0.0f, glass_eta = 0.0f, glass_r0 = 0.0f;
+        // A shape's record carries what the event needs in the form the event uses it (rt_device.h): its class
+        // (0 ends the path and returns throughput x colour x `emit`; 1 Lambertian, 2 metal, 3 dielectric, 4 debug)
+        // and `emit` = 1 for a light (LightSource::emit / glsl:278-280) and for a material the shader does not know
+        // (whose colour is stored as 1: glsl:253,282-284 returns the throughput), 0 otherwise — so that the colour
+        // a path returns is a product, not a chain of cases.  A miss reads the record behind the shapes' (class 0,
+        // emit 0).  Colours are taken to be finite (0 x colour = 0).
         const float t_hit = __uint_as_float(best_key + Window<SEM>::tmin);
         const V3 p = madd(t_hit, d, o);                               // Ray::at / glsl:239
-        if (best_id != NONE) {
-            if (HAS_QUEUES && best_id >= n_shapes) {
-                V3 a = xyz(tri[4u * slot_of[best_id - n_shapes] + 1u]);
-                n = a * sign_(-dot(d, a));                            // glsl:165-167,272
-                att = v3(P.tri_albedo[0], P.tri_albedo[1], P.tri_albedo[2]);
-                if (HAS_TCOL && L.tcol_off != 0u) att = xyz(blob[L.tcol_off + (best_id - n_shapes)]);
-                type = 1u;
-            } else {
-                const float4 r0 = rec[4u * best_id], r1 = rec[4u * best_id + 1u];
-                const uint32_t tag = __float_as_uint(r1.w);
-                const uint32_t stype = tag >> 16;
-                type = tag & 0xffffu;
-                att = xyz(r1);
-                // An instance without boxes, triangles and cubes is launched only for scenes in which every shape that can
-                // be hit is a sphere.
-                if ((!HAS_QUEUES && !HAS_CUBE) || stype == 0u) n = normalize(v3(p.x - r0.x, p.y - r0.y, p.z - r0.z));      // scene.h:130-132
-                else if (HAS_QUEUES && stype == 1u) { const float4 r3 = rec[4u * best_id + 3u]; n = box_normal(xyz(r0), rec[4u * best_id + 2u].z, r3.z, r3.w, p); }
-                else if (HAS_CUBE && stype == 3u) {
-                    // rotation^T * normalAt(inPoint), scene.h:150-164,196: the row of the rotation that
-                    // belongs to the largest |coordinate| of the point in the cube's frame (first of
-                    // equals); the sign there is taken from an absolute value, so it is always +.
-                    const uint32_t ci = 4u * __float_as_uint(rec[4u * best_id + 2u].w);
-                    const float4 c0 = cub[ci], c1 = cub[ci + 1u], c2 = cub[ci + 2u];
-                    V3 ip;
-                    (void)hit_cube(c0, c1, c2, o, d, ip);
-                    const float ax = __builtin_fabsf(ip.x), ay = __builtin_fabsf(ip.y), az = __builtin_fabsf(ip.z);
-                    const bool y_gt = ay > ax;
-                    const float m1 = y_gt ? ay : ax;
-                    const bool z_gt = az > m1;
-                    n = z_gt ? xyz(c2) : (y_gt ? xyz(c1) : xyz(c0));
-                }
-                else n = v3(1.0f, 1.0f, 1.0f);                        // glsl:203
-                if (SEM == 0 && type == 2u) fuzz = rec[4u * best_id + 2u].x;
-                if (HAS_GLASS && type == 3u) { const float4 r3 = rec[4u * best_id + 3u]; glass_eta = r3.x; glass_r0 = r3.y; }
-            }
+        const bool is_tri = HAS_QUEUES && (best_id - n_shapes) < L.n_tris;       // a miss (NONE) wraps far beyond
+        const uint32_t rid = min(best_id, n_shapes);
+        const float4 r0 = rec[4u * rid], r1 = rec[4u * rid + 1u];
+        float4 r2 = rec[4u * rid + 2u];
+        asm volatile("" : "+v"(r2.w));                                // one 16-byte LDS read
+        const uint32_t tag = __float_as_uint(r1.w);
+        uint32_t cls = tag >> 24;
+        const uint32_t stype = (tag >> 16) & 0xffu;
+        V3 n, att = xyz(r1);
+        float emit = r2.y, fuzz = r2.x, glass_eta = 0.0f, glass_r0 = 0.0f;
+        // An instance without boxes, triangles and cubes is launched only for scenes in which every shape that can
+        // be hit is a sphere.
+        if ((!HAS_QUEUES && !HAS_CUBE) || stype == 0u) n = normalize(v3(p.x - r0.x, p.y - r0.y, p.z - r0.z));      // scene.h:130-132
+        else if (HAS_QUEUES && stype == 1u) { const float4 r3 = rec[4u * rid + 3u]; n = box_normal(xyz(r0), r2.z, r3.z, r3.w, p); }
+        else if (HAS_CUBE && stype == 3u) {
+            // rotation^T * normalAt(inPoint), scene.h:150-164,196: the row of the rotation that
+            // belongs to the largest |coordinate| of the point in the cube's frame (first of
+            // equals); the sign there is taken from an absolute value, so it is always +.
+            const uint32_t ci = 4u * __float_as_uint(r2.w);
+            const float4 c0 = cub[ci], c1 = cub[ci + 1u], c2 = cub[ci + 2u];
+            V3 ip;
+            (void)hit_cube(c0, c1, c2, o, d, ip);
+            const float ax = __builtin_fabsf(ip.x), ay = __builtin_fabsf(ip.y), az = __builtin_fabsf(ip.z);
+            const bool y_gt = ay > ax;
+            const float m1 = y_gt ? ay : ax;
+            const bool z_gt = az > m1;
+            n = z_gt ? xyz(c2) : (y_gt ? xyz(c1) : xyz(c0));
+        }
+        else n = v3(1.0f, 1.0f, 1.0f);                                // glsl:203
+        if (HAS_GLASS && cls == 3u) { const float4 r3 = rec[4u * rid + 3u]; glass_eta = r3.x; glass_r0 = r3.y; }
+        if (is_tri) {
+            V3 a = xyz(tri[4u * slot_of[best_id - n_shapes] + 1u]);
+            n = a * sign_(-dot(d, a));                                // glsl:165-167,272
+            att = v3(P.tri_albedo[0], P.tri_albedo[1], P.tri_albedo[2]);
+            if (HAS_TCOL && L.tcol_off != 0u) att = xyz(blob[L.tcol_off + (best_id - n_shapes)]);
+            cls = 1u; emit = 0.0f; fuzz = 0.0f;
         }
         if (TRACE) {
             size_t at = (size_t)pixel * P.max_depth + bounce;
             trace_hit[at] = (int32_t)best_id;
-            trace_mat[at] = type;
+            trace_mat[at] = best_id == NONE ? NONE : (is_tri ? 1u : (tag & 0xffffu));
         }
 
         const bool last = bounce + 1u >= P.max_depth;                 // rayTracer.h:113-115 / glsl:263,287
-        bool ended = true;
         bool raw_dir = false;                                         // new direction is used as it is
-        V3 color = v3(0, 0, 0);                                       // what the path returns if it ends here
         V3 v = v3(0, 0, 1);                                           // new direction before normalisation
-        const bool diffuse = type == 1u, metal = type == 2u, glass = HAS_GLASS && type == 3u;
+        const bool diffuse = cls == 1u, metal = cls == 2u, glass = HAS_GLASS && cls == 3u;
         if (STATS) { n_diffuse += diffuse ? 1u : 0u; n_specular += (metal || glass) ? 1u : 0u; }
         const V3 ta = thr * att;                                      // a light returns it, a bounce carries it on
-        if (type == 0u) color = ta;                                   // LightSource::emit / glsl:278-280
-        else if (type == 100u) color = (SEM == 0) ? thr * n : n;      // glsl:248-252
-        else if (!diffuse && !metal && !glass && type != NONE) color = (SEM == 0) ? v3(0, 0, 0) : thr;   // glsl:253,282-284
-        else if ((diffuse || metal || glass) && !last) ended = false;
+        V3 color = ta * emit;                                         // what the path returns if it ends here
+        if (L.has_debug != 0u && cls == 4u) color = (SEM == 0) ? thr * n : n;    // glsl:248-252
+        bool ended = !(cls - 1u < (HAS_GLASS ? 3u : 2u)) || last;
 
         // Two draws per lane: the bounce's pair, or — for a lane that starts a
         // sample — the jitter pair of the new sample.
@@ -1077,8 +1078,9 @@ void trace_kernel(const TraceParams P,
                 v = madd(-(2.0f * dot(d, n)), n, d);                  // glsl:243-247; reflect :82-84
             }
         }
-        const V3 nd = normalize(v);
-        d = v3(raw_dir ? v.x : nd.x, raw_dir ? v.y : nd.y, raw_dir ? v.z : nd.z);   // per component: a struct select goes through scratch memory
+        // normalize(v), or v as it is: one select on the factor instead of three on the components (v * 1 = v)
+        const float inv_len = raw_dir ? 1.0f : rsqrt_nr(dot(v, v));
+        d = v * inv_len;
         RT_PHASE_MARK(3)
     }
 

@@ -49,8 +49,8 @@ PHASES = [
     ("kernel: boxes / cubes / tree walk", "        // The lanes still tracing, and this lane's place among them", "        // ---- the surface"),
     ("kernel: surface (record, normal, material)", "        // ---- the surface", "        // Two draws per lane: the bounce's pair"),
     ("kernel: accumulate + draws", "        // Two draws per lane: the bounce's pair", "        if (ended) {\n            o = camera_origin"),
-    ("kernel: restart / scatter", "        if (ended) {\n            o = camera_origin", "        const V3 nd = normalize(v);"),
-    ("kernel: new direction", "        const V3 nd = normalize(v);", "    if (!TRACE && valid) {\n        if (CAN_SLICE"),
+    ("kernel: restart / scatter", "        if (ended) {\n            o = camera_origin", "        // normalize(v), or v as it is"),
+    ("kernel: new direction", "        // normalize(v), or v as it is", "    if (!TRACE && valid) {\n        if (CAN_SLICE"),
     ("kernel: write-back", "    if (!TRACE && valid) {\n        if (CAN_SLICE", "// Turns the per-tile costs"),
 ]
 
