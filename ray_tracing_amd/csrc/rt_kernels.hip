@@ -169,12 +169,17 @@ RT_DEV void draw_pair(uint32_t key, uint32_t pair, float& a, float& b)
 {
     const uint32_t x = hash32(key + pair * 0x9e3779b9u);
     const uint32_t y = x * 0xadb4a92du;
-    a = (float)(x >> 8) * 0x1p-24f;
-    b = (float)(y >> 8) * 0x1p-24f;
+    a = (float)(x >> 8);
+    b = (float)(y >> 8);
 }
+// A draw travels as the integer it is made of, 0 .. 2^24 - 1 as a float ("raw"); the value in [0, 1) is raw * 2^-24.
+// Scaling by a power of two is exact, so every consumer folds the factor into a constant it multiplies by anyway
+// (fma(-2, u, 1) = fma(-2^-23, raw, 1) to the last bit) and the two multiplications per pair are never issued.
+constexpr float RAW = 0x1p-24f;
 RT_DEV uint32_t bounce_pair(uint32_t bounce) { return 1u + 2u * bounce; }
 
 RT_DEV void sincos2pi(float u, float& c_out, float& s_out);
+RT_DEV void sincos2pi_raw(float a, float& c_out, float& s_out);
 
 // random() of RayTracing.glsl:44-51, the shader's own stream, for contexts created with
 // RT_RNG_GLSL: the state is the vec3 `seed` of RayTracing.glsl:9; every draw adds (1.78, 3.1,
@@ -197,9 +202,13 @@ RT_DEV float glsl_random(V3& s)
 // angle h = pi*u - pi/2 lies in [-pi/2, pi/2), where one odd and one even Taylor
 // polynomial (Horner form) give sin h and cos h; then cos(2 pi u) = sin^2 h -
 // cos^2 h and sin(2 pi u) = -2 sin h cos h.
-RT_DEV void sincos2pi(float u, float& c_out, float& s_out)
+RT_DEV void sincos_half(float x, float& c_out, float& s_out);
+RT_DEV void sincos2pi(float u, float& c_out, float& s_out) { sincos_half(fma_(u, 0x1.921fb6p+1f, -0x1.921fb6p+0f), c_out, s_out); }
+// the same for a raw draw: u * pi = raw * (pi * 2^-24), both products exact to the same real number
+RT_DEV void sincos2pi_raw(float a, float& c_out, float& s_out) { sincos_half(fma_(a, 0x1.921fb6p+1f * RAW, -0x1.921fb6p+0f), c_out, s_out); }
+// x = the half angle pi*u - pi/2
+RT_DEV void sincos_half(float x, float& c_out, float& s_out)
 {
-    float x = fma_(u, 0x1.921fb6p+1f, -0x1.921fb6p+0f);
     float x2 = x * x;
     float ps = -0x1.ae6456p-26f;
     ps = fma_(ps, x2, 0x1.71de3ap-19f);
@@ -220,22 +229,22 @@ RT_DEV void sincos2pi(float u, float& c_out, float& s_out)
 }
 
 // A point uniform on the unit sphere: what randomUnitVector() of
-// src/utils.h:37-46 (three normal deviates, normalised) is distributed as.
-RT_DEV V3 unit_vector(float u1, float u2)
+// src/utils.h:37-46 (three normal deviates, normalised) is distributed as.  Raw draws.
+RT_DEV V3 unit_vector(float a1, float a2)
 {
-    float z = fma_(-2.0f, u1, 1.0f);
+    float z = fma_(-2.0f * RAW, a1, 1.0f);
     float r = sqrt_rn(fma_(-z, z, 1.0f));            // 1 - z*z is 0 or >= 2^-23
     float c, s;
-    sincos2pi(u2, c, s);
+    sincos2pi_raw(a2, c, s);
     return v3(r * c, r * s, z);
 }
 
 // randomOnHalfUnitShere, RayTracing.glsl:64-80.
-RT_DEV V3 hemisphere_glsl(V3 n, float u1, float u2)
+RT_DEV V3 hemisphere_glsl(V3 n, float a1, float a2)            // raw draws
 {
     float c, s;
-    sincos2pi(u1, c, s);
-    float r = u2;
+    sincos2pi_raw(a1, c, s);
+    float r = a2 * RAW;
     float dist = sqrt_rn(fma_(-r, r, 1.0f));         // 1 - r*r >= 2^-24
     float x = c * dist, y = s * dist;
     float q = fma_(n.x, n.x, n.y * n.y);          // |(-n.y, n.x, 0)|^2
@@ -545,14 +554,21 @@ void trace_kernel(const TraceParams P,
     // two draws) or renderPixel<N>, src/cpu_version/rayTracer.h:92-101 (grid).
     V3 pcur = pc;                      // of the pixel this lane is tracing (POOL: not always its own)
     uint32_t cgx = gx, cgy = gy;
-    auto camera_origin = [&](uint32_t smp, float u1, float u2) -> V3 {
+    // The jitter's vectors in vector registers (an operand from a scalar register halves the issue rate of the six
+    // fused multiply-adds of every new camera ray), and the pixel step times 2^-24 for raw draws.
+    V3 right_v = cam_right, up_v = cam_up;
+    float kstep = step * RAW;
+    // Only where registers are to spare: the instances with queues or cubes / dielectrics are at their budget.
+    if (GEO == 0) asm volatile("" : "+v"(right_v.x), "+v"(right_v.y), "+v"(right_v.z), "+v"(up_v.x), "+v"(up_v.y), "+v"(up_v.z), "+v"(kstep));
+    auto camera_origin = [&](uint32_t smp, float a1, float a2) -> V3 {       // raw draws
         if (P.sample_mode == 0u) {
-            float s1 = step * u1, s2 = step * u2;
-            return madd(-s2, cam_up, madd(s1, cam_right, pcur));
+            float s1 = kstep * a1, s2 = kstep * a2;                          // step * u, RayTracing.glsl:296
+            return madd(-s2, up_v, madd(s1, right_v, pcur));
         }
         const uint32_t N = P.grid_n;
         const uint32_t i = (smp / N) % N, j = smp % N;
-        const float step_size = step / (float)(N + 1u);
+        float step_size = step / (float)(N + 1u);
+        asm volatile("" : "+v"(step_size));                                  // computed where it is used: the grid's six step vectors would otherwise sit in registers through every launch
         const V3 ups = cam_up * step_size, rs = cam_right * step_size;
         V3 org = pcur - ups * (float)i;
         if (P.sample_mode == 2u) {
@@ -579,7 +595,7 @@ void trace_kernel(const TraceParams P,
         if (RNG_GLSL) {
             state = glsl_seed(smp);
             a = b = 0.0f;
-            if (P.sample_mode == 0u) { a = glsl_random(state); b = glsl_random(state); }   // the grid modes draw nothing here
+            if (P.sample_mode == 0u) { a = glsl_random(state) * (1.0f / RAW); b = glsl_random(state) * (1.0f / RAW); }   // the grid modes draw nothing here
         }
         else draw_pair(k, 0u, a, b);
     };
@@ -1005,14 +1021,14 @@ void trace_kernel(const TraceParams P,
             }
             if (ended) { pcur = npc; key = nh1 + sample * SAMPLE_STEP; }
         }
-        float u1, u2;
+        float u1, u2;                                                 // raw draws
         if (RNG_GLSL) {
             // The shader draws only where its program does: two values for a new camera ray,
             // two for a diffuse bounce (angle, then r: glsl:66-67), two for a fuzzy reflection
             // of the CPU rules, none for a mirror.
             if (ended) gs = glsl_seed(sample);
             V3 g = gs;
-            u1 = glsl_random(g); u2 = glsl_random(g);
+            u1 = glsl_random(g) * (1.0f / RAW); u2 = glsl_random(g) * (1.0f / RAW);      // raw, like the hash's draws
             const bool uses = (ended && P.sample_mode == 0u) || (!ended && (diffuse || glass || (SEM == 0 && metal && fuzz != 0.0f)));
             gs = v3(uses ? g.x : gs.x, uses ? g.y : gs.y, uses ? g.z : gs.z);
         } else {
@@ -1046,7 +1062,7 @@ void trace_kernel(const TraceParams P,
                 const float par = -sqrt_rn(__builtin_fabsf(1.0f - dot(perp, perp)));
                 const V3 refr = madd(par, n, perp);
                 const V3 mirr = madd(-(2.0f * dot(d, n)), n, d);
-                const bool mirror = u1 < refl;
+                const bool mirror = u1 * RAW < refl;
                 v = v3(mirror ? mirr.x : refr.x, mirror ? mirr.y : refr.y, mirror ? mirr.z : refr.z);
             } else if (SEM == 0) {
                 // Metal::scatter, scene.h:73-81; reflect, utils.h:62-64
