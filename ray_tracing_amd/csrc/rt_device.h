@@ -115,11 +115,12 @@ static_assert((64u / TREE_FAN - 1u) + (SPREAD_BELOW - 1u) <= NODE_STACK_STAGED, 
 static_assert((64u / TREE_FAN - 1u) + (SPREAD_BELOW - 1u) + (TREE_LEVELS - 2u) * (64u - 64u / TREE_FAN) + 64u <= NODE_STACK_GLOBAL,
               "the node stack of a mesh in global memory overflows");
 static_assert(TREE_LEVELS == 4u, "stack entries carry two bits of level, the walk has four nested loops");
-// Behind them: the sums of the wave's 64 pixels, three 32-bit words each, while the wave's lanes share its paths.
+// Behind them, while the wave's lanes share its paths: the sums of the wave's 64 pixels, three 32-bit words each,
+// and a table of the pixels' ray constants, 16 bytes each.
 #ifndef RT_POOL
 #define RT_POOL 1
 #endif
-constexpr uint32_t POOL_SUM_BYTES = RT_POOL ? 3u * 64u * 4u : 0u;
+constexpr uint32_t POOL_SUM_BYTES = RT_POOL ? 3u * 64u * 4u + 64u * 16u : 0u;
 constexpr uint32_t WAVE_LDS_WORDS = (QUEUE_ENTRIES * 4u + 64u * 8u + NODE_STACK_STAGED * 4u + POOL_SUM_BYTES) / 16u;
 constexpr uint32_t WAVE_LDS_WORDS_GLOBAL = (QUEUE_ENTRIES * 4u + 64u * 8u + NODE_STACK_GLOBAL * 4u + POOL_SUM_BYTES) / 16u;
 // The 16-byte words a workgroup of `group_waves` waves needs behind the staged scene.

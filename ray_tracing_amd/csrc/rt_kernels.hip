@@ -646,15 +646,19 @@ void trace_kernel(const TraceParams P,
     // mesh scene were spent waiting.  Under the shader's rules a pixel's sum is an integer sum and takes its terms in
     // any order, so the wave's paths — item k*64 + p = sample k of the pixel of lane p — are handed out in item order
     // to whichever lane is free: a lane whose path ends takes the next item (a count over the ended lanes, no
-    // atomics), fetches that pixel's ray constants from the pixel's home lane across the wave, and adds the path's
-    // colour to the pixel's sum in LDS.  The home lane writes the sums out at the end.  Waves of tiles that stick out
-    // of the frame keep the own-pixel order (their invalid lanes are not in the loop and cannot serve constants).
+    // atomics), reads that pixel's ray constants (its corner on the image plane, the hash of its index) from a
+    // table the wave keeps in LDS, and adds the path's colour to the pixel's sum there.  The home lane writes the
+    // sums out at the end.  Waves of tiles that stick out of the frame keep the own-pixel order.
     const uint32_t sample_begin = sample;
     const uint32_t n_items = 64u * (sample_end - sample_begin);
     const bool pool_on = POOL && __ballot(valid) == ~0ull;
     uint32_t item = lane, next_item = 64u, cur_p = lane;
     uint32_t* const pool_acc = node_stack + (TRI_GLOBAL ? NODE_STACK_GLOBAL : NODE_STACK_STAGED);   // [3][64]
-    if (POOL) { pool_acc[lane] = 0u; pool_acc[64u + lane] = 0u; pool_acc[128u + lane] = 0u; }
+    float4* const pool_pix = reinterpret_cast<float4*>(pool_acc + 192u);                             // [64]: {pc.xyz, h1}
+    if (POOL) {
+        pool_acc[lane] = 0u; pool_acc[64u + lane] = 0u; pool_acc[128u + lane] = 0u;
+        pool_pix[lane] = make_float4(pc.x, pc.y, pc.z, __uint_as_float(h1));
+    }
 #if RT_PHASE_CLOCKS
     uint32_t phase_clk[4] = { 0u, 0u, 0u, 0u }, phase_t = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
@@ -1000,6 +1004,9 @@ void trace_kernel(const TraceParams P,
                 cur_p = item & 63u;
                 sample = sample_begin + (item >> 6);
                 alive = item < n_items;
+                const float4 pp = pool_pix[cur_p];                         // the constants of the pixel the lane goes on with
+                pcur = xyz(pp);
+                key = __float_as_uint(pp.w) + sample * SAMPLE_STEP;
             } else {
                 ++sample;
                 alive = sample < sample_end;
@@ -1007,19 +1014,12 @@ void trace_kernel(const TraceParams P,
             }
             if (STATS && alive) ++n_samples;
         }
-        if (POOL) {
-            // the constants of the pixel a lane goes on with, from that pixel's home lane (every lane reads: a read
-            // across the wave cannot sit in a branch; lanes in mid-path read their own pixel's and drop them)
+        if (POOL && RNG_GLSL) {
+            // the shader's seed needs the pixel's coordinates: from the pixel's home lane (every lane reads: a read
+            // across the wave cannot sit in a branch; lanes in mid-path read their own pixel's again)
             const int from = (int)(cur_p << 2);
-            const V3 npc = v3(__uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(pc.x))),
-                              __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(pc.y))),
-                              __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(pc.z))));
-            const uint32_t nh1 = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)h1);
-            if (RNG_GLSL) {
-                const uint32_t ngx = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)gx), ngy = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)gy);
-                cgx = ended ? ngx : cgx; cgy = ended ? ngy : cgy;
-            }
-            if (ended) { pcur = npc; key = nh1 + sample * SAMPLE_STEP; }
+            const uint32_t ngx = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)gx), ngy = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)gy);
+            cgx = ended ? ngx : cgx; cgy = ended ? ngy : cgy;
         }
         float u1, u2;                                                 // raw draws
         if (RNG_GLSL) {
