@@ -973,7 +973,12 @@ void trace_kernel(const TraceParams P,
         if (STATS) { n_diffuse += diffuse ? 1u : 0u; n_specular += (metal || glass) ? 1u : 0u; }
         const V3 ta = thr * att;                                      // a light returns it, a bounce carries it on
         V3 color = ta * emit;                                         // what the path returns if it ends here
-        if (L.has_debug != 0u && cls == 4u) color = (SEM == 0) ? thr * n : n;    // glsl:248-252
+        if (L.has_debug != 0u) {
+            // a branch on the scene, not a select on every lane of every scene: the empty statement keeps the compiler
+            // from turning the block into three multiplications and three selects that always run
+            asm volatile("");
+            if (cls == 4u) color = (SEM == 0) ? thr * n : n;          // glsl:248-252
+        }
         bool ended = !(cls - 1u < (HAS_GLASS ? 3u : 2u)) || last;
 
         // Two draws per lane: the bounce's pair, or — for a lane that starts a

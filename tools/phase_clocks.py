@@ -20,6 +20,8 @@ t = tl.view(np.uint32).astype(np.int64)
 t[:, 2] &= 0x0fffffff
 tot = t.sum(axis=0) * 16
 names = ["sphere scan", "boxes / cubes", "triangle tree", "surface, draws, new direction"]
+if os.environ.get("PHASE_SPLIT") == "2":        # the library was built with -DRT_PHASE_CLOCKS=2
+    names = ["closest hit (all of it)", "record, normal", "accumulate, draws, scatter / restart", "new direction"]
 wi = max(1, st.wave_iterations)
 print(f"{name}: {st.wave_iterations} wave iterations, lane use {st.segments / (64 * wi):.3f}")
 for n, v in zip(names, tot):
