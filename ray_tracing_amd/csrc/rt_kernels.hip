@@ -52,10 +52,18 @@ namespace rtd {
 #ifndef RT_PHASE_CLOCKS
 #define RT_PHASE_CLOCKS 0
 #endif
-#if RT_PHASE_CLOCKS
-#define RT_PHASE_MARK(k) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); phase_clk[k] += now_ - phase_t; phase_t = now_; }
+// RT_PHASE_CLOCKS=2 splits the last of these instead: everything up to the closest hit / the surface's record and
+// normal / accumulation, draws and the scatter or restart / the new direction.
+#define RT_PHASE_MARK_(k) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); phase_clk[k] += now_ - phase_t; phase_t = now_; }
+#if RT_PHASE_CLOCKS == 1
+#define RT_PHASE_MARK(k) RT_PHASE_MARK_(k)
+#define RT_PHASE_MARK2(k)
+#elif RT_PHASE_CLOCKS == 2
+#define RT_PHASE_MARK(k)
+#define RT_PHASE_MARK2(k) RT_PHASE_MARK_(k)
 #else
 #define RT_PHASE_MARK(k)
+#define RT_PHASE_MARK2(k)
 #endif
 struct V3 { float x, y, z; };
 constexpr uint32_t WORK_NONE = 0xffffffffu;      // a plan entry without work
@@ -911,6 +919,7 @@ void trace_kernel(const TraceParams P,
             }
         }
         RT_PHASE_MARK(2)
+        RT_PHASE_MARK2(0)
         const uint32_t best_key = best.key, best_id = best.id;
         if (STATS) { ++n_segments; }
 
@@ -966,6 +975,7 @@ void trace_kernel(const TraceParams P,
             trace_mat[at] = best_id == NONE ? NONE : (is_tri ? 1u : (tag & 0xffffu));
         }
 
+        RT_PHASE_MARK2(1)
         const bool last = bounce + 1u >= P.max_depth;                 // rayTracer.h:113-115 / glsl:263,287
         bool raw_dir = false;                                         // new direction is used as it is
         V3 v = v3(0, 0, 1);                                           // new direction before normalisation
@@ -1099,10 +1109,12 @@ void trace_kernel(const TraceParams P,
                 v = madd(-(2.0f * dot(d, n)), n, d);                  // glsl:243-247; reflect :82-84
             }
         }
+        RT_PHASE_MARK2(2)
         // normalize(v), or v as it is: one select on the factor instead of three on the components (v * 1 = v)
         const float inv_len = raw_dir ? 1.0f : rsqrt_nr(dot(v, v));
         d = v * inv_len;
         RT_PHASE_MARK(3)
+        RT_PHASE_MARK2(3)
     }
 
     if (!TRACE && valid) {
