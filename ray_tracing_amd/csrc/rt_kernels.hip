@@ -325,25 +325,38 @@ RT_DEV void test_sphere(float4 s, uint32_t shape_id, V3 o, V3 d, Best& best)
 }
 
 // hitBox, RayTracing.glsl:138-156.  bx = centre.xyz, 1/side along x; iy, iz = 1/side along
-// y and z (the shader has one side for all three, :139).
+// y and z (the shader has one side for all three, :139).  The same values as the shader's expressions, from fewer
+// instructions (compares and selects issue at half the rate of the arithmetic here):
+//   * t = (0.5 - ob*sign(ob)) / (sign(ob)*db), :144-145: ob*sign(ob) is |ob|, and sign(ob)*db is db with ob's sign bit
+//     flipped in — or 0 where ob is 0 (or -0), which keeps that axis' "no candidate" (t = NaN);
+//   * max(|p.x|, |p.y|, |p.z|), :150: the hardware's three-way maximum differs from GLSL's max only when an operand is a
+//     NaN, and a NaN coordinate comes either with all three NaN or with an infinite one: rejected both ways;
+//   * 0.4999 < m < 0.5001, :151: one unsigned compare of bit patterns (m is non-negative or a NaN).
+RT_DEV float box_slab(float obk, float dbk)
+{
+    const uint32_t flip = __float_as_uint(obk) & 0x80000000u;
+    float den = __uint_as_float(__float_as_uint(dbk) ^ flip);
+    den = (obk == 0.0f) ? 0.0f : den;
+    return (0.5f - __builtin_fabsf(obk)) * rcp_nr(den);
+}
 RT_DEV float hit_box(float4 bx, float iy, float iz, V3 o, V3 d)
 {
     const float ix = bx.w;
     V3 ob = v3(ix * (o.x - bx.x), iy * (o.y - bx.y), iz * (o.z - bx.z));
     V3 db = v3(ix * d.x, iy * d.y, iz * d.z);
-    V3 sg = v3(sign_(ob.x), sign_(ob.y), sign_(ob.z));
     float t[3];
-    t[0] = (0.5f - ob.x * sg.x) * rcp_nr(sg.x * db.x);
-    t[1] = (0.5f - ob.y * sg.y) * rcp_nr(sg.y * db.y);
-    t[2] = (0.5f - ob.z * sg.z) * rcp_nr(sg.z * db.z);
+    t[0] = box_slab(ob.x, db.x);
+    t[1] = box_slab(ob.y, db.y);
+    t[2] = box_slab(ob.z, db.z);
+    constexpr uint32_t LO = __builtin_bit_cast(uint32_t, 0.4999f), HI = __builtin_bit_cast(uint32_t, 0.5001f);
+    static_assert(LO < HI, "window");
     float best = __builtin_inff();
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        float px = __builtin_fabsf(fma_(db.x, t[k], ob.x));
-        float py = __builtin_fabsf(fma_(db.y, t[k], ob.y));
-        float pz = __builtin_fabsf(fma_(db.z, t[k], ob.z));
-        float inf_norm = gmax(px, gmax(py, pz));
-        if (inf_norm < 0.5001f && inf_norm > 0.4999f && best > t[k]) best = t[k];
+        const float px = fma_(db.x, t[k], ob.x), py = fma_(db.y, t[k], ob.y), pz = fma_(db.z, t[k], ob.z);
+        const float inf_norm = __builtin_fmaxf(__builtin_fabsf(px), __builtin_fmaxf(__builtin_fabsf(py), __builtin_fabsf(pz)));
+        const bool on_face = __float_as_uint(inf_norm) - (LO + 1u) < HI - (LO + 1u);
+        if (on_face && best > t[k]) best = t[k];
     }
     return best;
 }
@@ -352,9 +365,11 @@ RT_DEV float hit_box(float4 bx, float iy, float iz, V3 o, V3 d)
 RT_DEV V3 box_normal(V3 c, float rx, float ry, float rz, V3 p)
 {
     float qx = (p.x - c.x) * rx, qy = (p.y - c.y) * ry, qz = (p.z - c.z) * rz;
-    V3 n = v3(((__builtin_fabsf(qx) < 0.499f) ? 0.0f : 1.0f) * sign_(qx),
-              ((__builtin_fabsf(qy) < 0.499f) ? 0.0f : 1.0f) * sign_(qy),
-              ((__builtin_fabsf(qz) < 0.499f) ? 0.0f : 1.0f) * sign_(qz));
+    // step(0.499, |q|) * sign(q): 0 below 0.499 — where q = 0 lies too — and otherwise 1 with q's sign (q is a finite
+    // number here: the point of a hit)
+    V3 n = v3((__builtin_fabsf(qx) < 0.499f) ? 0.0f : __builtin_copysignf(1.0f, qx),
+              (__builtin_fabsf(qy) < 0.499f) ? 0.0f : __builtin_copysignf(1.0f, qy),
+              (__builtin_fabsf(qz) < 0.499f) ? 0.0f : __builtin_copysignf(1.0f, qz));
     return normalize(n);
 }
 
