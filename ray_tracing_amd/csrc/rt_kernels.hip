@@ -55,15 +55,20 @@ namespace rtd {
 // RT_PHASE_CLOCKS=2 splits the last of these instead: everything up to the closest hit / the surface's record and
 // normal / accumulation, draws and the scatter or restart / the new direction.
 #define RT_PHASE_MARK_(k) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); phase_clk[k] += now_ - phase_t; phase_t = now_; }
+// RT_PHASE_CLOCKS=3: the triangle tree alone: everything else / the walk by the whole wave and the queueing / the
+// passes over queued nodes / the passes over queued leaves.
+#define RT_PHASE_MARK(k)
+#define RT_PHASE_MARK2(k)
+#define RT_PHASE_MARK3(k)
 #if RT_PHASE_CLOCKS == 1
+#undef RT_PHASE_MARK
 #define RT_PHASE_MARK(k) RT_PHASE_MARK_(k)
-#define RT_PHASE_MARK2(k)
 #elif RT_PHASE_CLOCKS == 2
-#define RT_PHASE_MARK(k)
+#undef RT_PHASE_MARK2
 #define RT_PHASE_MARK2(k) RT_PHASE_MARK_(k)
-#else
-#define RT_PHASE_MARK(k)
-#define RT_PHASE_MARK2(k)
+#elif RT_PHASE_CLOCKS == 3
+#undef RT_PHASE_MARK3
+#define RT_PHASE_MARK3(k) RT_PHASE_MARK_(k)
 #endif
 struct V3 { float x, y, z; };
 constexpr uint32_t WORK_NONE = 0xffffffffu;      // a plan entry without work
@@ -787,6 +792,7 @@ void trace_kernel(const TraceParams P,
             }
         }
         RT_PHASE_MARK(1)
+        RT_PHASE_MARK3(0)
         // Triangles: walk the four-level bounding-sphere tree with the whole wave; a subtree is entered when the
         // ray of any live lane can touch its sphere.  At a leaf only the lanes whose rays touch it have any business
         // with its triangles — typically a few of the 64, since bounce rays share little — so they do not test
@@ -799,6 +805,7 @@ void trace_kernel(const TraceParams P,
             const uint32_t per_pass = n_live / TREE_LEAF;         // pairs one pass takes: TREE_LEAF lanes each
             uint32_t q_head = 0u, q_len = 0u;                     // wave-uniform
             auto pass = [&](uint32_t count) {
+                RT_PHASE_MARK3(1)
                 const uint32_t e = lane_rank / TREE_LEAF, k = lane_rank % TREE_LEAF;
                 const bool work = e < count;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -822,6 +829,7 @@ void trace_kernel(const TraceParams P,
                         atomicMin(&found[src], ((unsigned long long)ckey << 32) | cid);
                     if (STATS) ++n_tri;
                 }
+                RT_PHASE_MARK3(3)
             };
             // Pairs (lane, leaf) go to the triangle queue; full passes are run at once.
             auto push_leaves = [&](bool touch, uint32_t src, uint32_t leaf) {
@@ -850,6 +858,7 @@ void trace_kernel(const TraceParams P,
                 ns_len += (uint32_t)__popcll(touching);
             };
             auto bound_pass = [&](uint32_t count) {
+                RT_PHASE_MARK3(1)
                 const uint32_t e = lane_rank / TREE_FAN, c = lane_rank % TREE_FAN;
                 const bool work = e < count;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -871,6 +880,7 @@ void trace_kernel(const TraceParams P,
                 const bool touch = valid && bound_hit<SEM>(nodes[children_at + (valid ? child : 0u)], ro, rd, rkey);
                 if (STATS && valid) ++n_node;
                 if (DEEP) push_nodes(touch && level != 1u, src, level - 1u, child);
+                RT_PHASE_MARK3(2)
                 push_leaves(touch && level == 1u, src, child);
             };
             // -> the node was put on the stack (few lanes touch it) and full passes were run
@@ -934,6 +944,7 @@ void trace_kernel(const TraceParams P,
             }
         }
         RT_PHASE_MARK(2)
+        RT_PHASE_MARK3(1)
         RT_PHASE_MARK2(0)
         const uint32_t best_key = best.key, best_id = best.id;
         if (STATS) { ++n_segments; }

@@ -20,6 +20,8 @@ t = tl.view(np.uint32).astype(np.int64)
 t[:, 2] &= 0x0fffffff
 tot = t.sum(axis=0) * 16
 names = ["sphere scan", "boxes / cubes", "triangle tree", "surface, draws, new direction"]
+if os.environ.get("PHASE_SPLIT") == "3":        # -DRT_PHASE_CLOCKS=3
+    names = ["everything but the triangle tree", "walk by the whole wave, queueing", "passes over queued nodes", "passes over queued leaves"]
 if os.environ.get("PHASE_SPLIT") == "2":        # the library was built with -DRT_PHASE_CLOCKS=2
     names = ["closest hit (all of it)", "record, normal", "accumulate, draws, scatter / restart", "new direction"]
 wi = max(1, st.wave_iterations)
