@@ -86,6 +86,8 @@ struct rt_ctx {
     // Switches for measurements, read from the environment once, when the context is created.
     uint32_t group_waves = 4;           // waves per workgroup (RT_GROUP_WAVES: 1 .. 8, for measurements)
     bool env_no_tile_order = false, env_no_slices = false, env_mesh_in_lds = false, env_no_probe = false;
+    float slice_share = 0.25f, slice_early = 0.5f;       // RT_SLICE_SHARE, RT_SLICE_EARLY (measurements)
+    uint32_t slice_min_spp = 16u, slice_max = 16u;       // RT_SLICE_MIN_SPP, RT_SLICE_MAX
 };
 
 static thread_local std::string g_create_error;
@@ -525,6 +527,10 @@ int rt_create(rt_ctx** out, const rt_config* cfg)
     ctx->env_no_slices = env_on("RT_NO_SLICES");
     ctx->env_mesh_in_lds = env_on("RT_MESH_IN_LDS");
     ctx->env_no_probe = env_on("RT_NO_PROBE");
+    if (const char* v = getenv("RT_SLICE_SHARE")) { const float f = (float)atof(v); if (f > 0.0f) ctx->slice_share = f; }
+    if (const char* v = getenv("RT_SLICE_EARLY")) { const float f = (float)atof(v); if (f > 0.0f) ctx->slice_early = f; }
+    if (const char* v = getenv("RT_SLICE_MIN_SPP")) { const int n = atoi(v); if (n >= 1) ctx->slice_min_spp = (uint32_t)n; }
+    if (const char* v = getenv("RT_SLICE_MAX")) { const int n = atoi(v); if (n >= 1 && n <= 16) ctx->slice_max = (uint32_t)n; }
     *out = ctx;
     return RT_OK;
 }
@@ -725,7 +731,7 @@ static int ensure_tiles(rt_ctx* ctx, const rtd::TraceParams& P)
 static uint32_t slices_allowed(const rt_ctx* ctx, uint32_t spp)
 {
     if (ctx->cfg.semantics != RT_SEM_GLSL || spp >= (1u << 24) || ctx->env_no_slices) return 1u;
-    return std::min(16u, std::max(1u, spp / 16u));
+    return std::min(ctx->slice_max, std::max(1u, spp / ctx->slice_min_spp));
 }
 
 // Turns the tile costs in `cost` into the plan of a launch of `spp` samples per pixel -> its number of workgroups.
@@ -735,10 +741,10 @@ static int make_plan(rt_ctx* ctx, uint32_t* cost, uint32_t* order, uint32_t n_ti
     const uint32_t extra = max_slices > 1u ? n_tiles : 0u;
     // A tile is cut when it costs more than a quarter of an even share (measured: 0.5 -> 48 ms, 0.35 -> 45,
     // 0.25 -> 41, 0.125 -> 41 on the 292-triangle mesh scene; no effect on scenes without expensive tiles).
-    const float share = 0.25f;
+    const float share = ctx->slice_share;
     // Uncut tiles above half the cutting threshold are as long as the slices and follow them directly (measured on the
     // same scene: 41.0 ms without, 39.1-40.3 ms with; putting them before the slices instead: the same).
-    const float early_share = 0.5f;
+    const float early_share = ctx->slice_early;
     RT_HIP(ctx, rtd::launch_tile_plan(ctx->stream, cost, order, n_tiles, extra, max_slices, share, early_share));
     *plan_units = n_tiles + extra;
     return RT_OK;
