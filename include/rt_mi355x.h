@@ -103,7 +103,11 @@ enum rt_flags {
     /* Box::Box stores three sides on the diagonal of `transformation` (shape.h:67), but the
      * shader reads only transformation[0][0] for all axes (RayTracing.glsl:139,159), so every
      * Box is a cube there — the default here too.  With this flag a Box has its three sides. */
-    RT_FLAG_BOX_SIDES          = 1u << 1
+    RT_FLAG_BOX_SIDES          = 1u << 1,
+    /* randomUnitVector() as the CPU tracer writes it (src/utils.h:45): three normal deviates, normalised
+     * (Box-Muller on four draws per event), instead of the direct sphere point that has the same
+     * distribution and is the default.  RT_SEM_CPU with RT_RNG_HASH only. */
+    RT_FLAG_UNIT_GAUSS         = 1u << 2
 };
 
 /* Which stream feeds the random draws. */

@@ -17,7 +17,7 @@ SAMPLE_JITTER, SAMPLE_GRID, SAMPLE_GRID_COMPAT = 0, 1, 2
 COLOR_AS_WRITTEN, COLOR_FORWARD = 0, 1
 UNIT_DIRECT, UNIT_GAUSS = 0, 1
 RNG_HASH, RNG_GLSL = 0, 1
-FLAG_METAL_UNNORMALIZED, FLAG_BOX_SIDES = 1, 2
+FLAG_METAL_UNNORMALIZED, FLAG_BOX_SIDES, FLAG_UNIT_GAUSS = 1, 2, 4
 ARITH_RECIPE, ARITH_LITERAL = 0, 1
 
 
@@ -57,6 +57,7 @@ def _load():
     lib.orc_convert.argtypes = [vp, vp, u32, u32, u32, u32, u32]
     lib.orc_set_arith.restype = None; lib.orc_set_arith.argtypes = [C.c_int]
     lib.orc_hash32.restype = u32; lib.orc_hash32.argtypes = [u32]
+    lib.orc_log_draw.restype = C.c_float; lib.orc_log_draw.argtypes = [C.c_float]
     lib.orc_path_key.restype = u32; lib.orc_path_key.argtypes = [u64, u32, u32]
     lib.orc_draw.restype = C.c_float; lib.orc_draw.argtypes = [u32, u32]
     lib.orc_glsl_random.restype = C.c_float; lib.orc_glsl_random.argtypes = [fp]
@@ -246,3 +247,8 @@ def mesh_triangles(path, main_cpp_pipeline=True, max_tris=8192):
     if n < 0:
         raise IOError(f"orc_mesh_triangles({path}) -> {n}")
     return out[:n].copy(), nv.value
+
+
+def log_draw(u):
+    """ln(u) of a draw u = k * 2^-24 by the oracle's fixed recipe."""
+    return float(lib.orc_log_draw(u))

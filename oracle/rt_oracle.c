@@ -10,8 +10,8 @@
  * explicit fmaf(), everything else is a separately rounded IEEE-754 binary32
  * operation, so a second implementation can match it bit for bit.  No libm
  * function other than sqrtf/fmaf/fabsf (all exactly rounded) feeds geometry;
- * the ORC_UNIT_GAUSS sampler, which uses logf/cosf/sinf, exists only for a
- * statistical cross-check.
+ * the ORC_UNIT_GAUSS sampler (src/utils.h:45 as written: three normal deviates, normalised) has a recipe
+ * of its own for the logarithm (orc_log_draw) and uses libm only in the literal arithmetic.
  *
  * Arithmetic conventions used throughout (ORC_ARITH_RECIPE; ORC_ARITH_LITERAL, further down, drops them):
  *   dot(a,b)      = fmaf(a.z,b.z, fmaf(a.y,b.y, a.x*b.x))
@@ -244,10 +244,44 @@ static v3 unit_vector_gauss(pathrng* g, uint32_t base)
     float u3 = rdraw(g, base + 2), u4 = rdraw(g, base + 3);
     if (u1 < 0x1p-24f) u1 = 0x1p-24f;
     if (u3 < 0x1p-24f) u3 = 0x1p-24f;
+    if (!t_lit) {
+        /* the recipe the HIP kernel repeats (RT_FLAG_UNIT_GAUSS): logarithm by orc_log_draw, sine and cosine
+         * by the shared polynomial, the exact square root; |.| because the logarithm of a draw next to 1 may
+         * come out as +1e-8 */
+        float r1 = sqrtf(fabsf(-2.0f * orc_log_draw(u1))), r2 = sqrtf(fabsf(-2.0f * orc_log_draw(u3)));
+        float c1, s1, c2, s2;
+        orc_sincos2pi(u2, &c1, &s1);
+        orc_sincos2pi(u4, &c2, &s2);
+        return normalize(V(r1 * c1, r1 * s1, r2 * c2));
+    }
     float r1 = sqrtf(-2.0f * logf(u1)), r2 = sqrtf(-2.0f * logf(u3));
     float a1 = 6.283185307179586f * u2, a2 = 6.283185307179586f * u4;
     v3 n = V(r1 * cosf(a1), r1 * sinf(a1), r2 * cosf(a2));
     return normalize(n);
+}
+
+/* ln(u) for a draw u = k * 2^-24, k = 1 .. 2^24 - 1, by a fixed recipe of IEEE operations: u = m * 2^e with m
+ * folded into [sqrt(1/2), sqrt(2)), ln m = f + f^2 q(f) for f = m - 1 with a degree-7 polynomial q (absolute
+ * error 4e-8 on the interval), plus e * ln 2. */
+float orc_log_draw(float u)
+{
+    float raw = u * 0x1p24f;                                  /* the integer the draw is made of; exact */
+    uint32_t b; memcpy(&b, &raw, 4);
+    int e = (int)(b >> 23) - 127;
+    uint32_t mb = (b & 0x007fffffu) | 0x3f800000u;
+    float m; memcpy(&m, &mb, 4);
+    if (m > 0x1.6a09e6p+0f) { m = m * 0.5f; e += 1; }
+    float f = m - 1.0f;
+    float q = 0x1.70cfe8p-4f;
+    q = fmaf(q, f, -0x1.23ffe8p-3f);
+    q = fmaf(q, f, 0x1.2f3c7ep-3f);
+    q = fmaf(q, f, -0x1.5374fcp-3f);
+    q = fmaf(q, f, 0x1.990c98p-3f);
+    q = fmaf(q, f, -0x1.000438p-2f);
+    q = fmaf(q, f, 0x1.555630p-2f);
+    q = fmaf(q, f, -0x1.fffffcp-2f);
+    float lm = fmaf(f * f, q, f);
+    return fmaf((float)(e - 24), 0x1.62e430p-1f, lm);
 }
 
 /* randomOnHalfUnitShere, RayTracing.glsl:64-80. */
@@ -497,7 +531,7 @@ static v3 shape_normal(const orc_params* prm, const orc_shape* s, v3 p)
 
 static v3 unit_vector(tracer* T, pathrng* g, uint32_t base)
 {
-    if (T->p->unit_sampler == ORC_UNIT_GAUSS) return unit_vector_gauss(g, base);
+    if (T->p->unit_sampler == ORC_UNIT_GAUSS || (T->p->flags & ORC_FLAG_UNIT_GAUSS)) return unit_vector_gauss(g, base);
     float u[3];
     float u1 = rdraw(g, base), u2 = rdraw(g, base + 1);
     orc_unit_vector(u1, u2, u);

@@ -32,7 +32,8 @@ typedef struct { float position[4]; float a[3]; float beta; float m1[4]; float m
 enum { ORC_SEM_CPU = 0, ORC_SEM_GLSL = 1 };
 enum { ORC_SAMPLE_JITTER = 0, ORC_SAMPLE_GRID = 1, ORC_SAMPLE_GRID_COMPAT = 2 };
 /* BOX_SIDES: a Box has the three sides Box::Box stores (shape.h:67) instead of the one the shader reads. */
-enum { ORC_FLAG_METAL_UNNORMALIZED = 1u, ORC_FLAG_BOX_SIDES = 2u };
+/* UNIT_GAUSS: randomUnitVector as written (src/utils.h:45); the same as unit_sampler = ORC_UNIT_GAUSS. */
+enum { ORC_FLAG_METAL_UNNORMALIZED = 1u, ORC_FLAG_BOX_SIDES = 2u, ORC_FLAG_UNIT_GAUSS = 4u };
 /* Which stream feeds the draws: the counter hash (one value per (seed, pixel, sample, draw
  * index)), or the shader's own random() (RayTracing.glsl:8-9,44-51), consumed in program order. */
 enum { ORC_RNG_HASH = 0, ORC_RNG_GLSL = 1 };
@@ -101,6 +102,7 @@ void orc_convert(uint32_t* accum, float* image_rgba, uint32_t width, uint32_t he
  * orc_set_arith(ORC_ARITH_LITERAL) was called on it. */
 void     orc_set_arith(int arith);
 uint32_t orc_hash32(uint32_t x);
+float    orc_log_draw(float u);
 uint32_t orc_path_key(uint64_t seed, uint32_t pixel_index, uint32_t sample);
 float    orc_draw(uint32_t key, uint32_t index);
 float    orc_glsl_random(float seed[3]);

@@ -499,6 +499,8 @@ int rt_create(rt_ctx** out, const rt_config* cfg)
     }
     if (c.semantics > RT_SEM_GLSL) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown semantics %u", c.semantics);
     if (c.rng > RT_RNG_GLSL) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown rng %u", c.rng);
+    if ((c.flags & RT_FLAG_UNIT_GAUSS) && (c.semantics != RT_SEM_CPU || c.rng != RT_RNG_HASH))
+        return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: RT_FLAG_UNIT_GAUSS needs RT_SEM_CPU and RT_RNG_HASH");
     if (c.sample_mode > RT_SAMPLE_GRID_COMPAT) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown sample_mode %u", c.sample_mode);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);

@@ -252,6 +252,42 @@ RT_DEV V3 unit_vector(float a1, float a2)
     return v3(r * c, r * s, z);
 }
 
+// ln(raw * 2^-24) for a raw draw 1 .. 2^24 - 1: raw = m * 2^e with m folded into [sqrt(1/2), sqrt(2)),
+// ln m = f + f^2 q(f), f = m - 1, q of degree 7 (4e-8 absolute), plus (e - 24) ln 2.  IEEE operations in a fixed
+// order: the oracle's orc_log_draw to the bit.
+RT_DEV float log_raw(float raw)
+{
+    const uint32_t b = __float_as_uint(raw);
+    int e = (int)(b >> 23) - 127;
+    float m = __uint_as_float((b & 0x007fffffu) | 0x3f800000u);
+    const bool fold = m > 0x1.6a09e6p+0f;
+    m = fold ? m * 0.5f : m;
+    e += fold ? 1 : 0;
+    const float f = m - 1.0f;
+    float q = 0x1.70cfe8p-4f;
+    q = fma_(q, f, -0x1.23ffe8p-3f);
+    q = fma_(q, f, 0x1.2f3c7ep-3f);
+    q = fma_(q, f, -0x1.5374fcp-3f);
+    q = fma_(q, f, 0x1.990c98p-3f);
+    q = fma_(q, f, -0x1.000438p-2f);
+    q = fma_(q, f, 0x1.555630p-2f);
+    q = fma_(q, f, -0x1.fffffcp-2f);
+    const float lm = fma_(f * f, q, f);
+    return fma_((float)(e - 24), 0x1.62e430p-1f, lm);
+}
+// randomUnitVector() as written, src/utils.h:45: three normal deviates (Box-Muller on four raw draws; the fourth
+// deviate is dropped), normalised.
+RT_DEV V3 unit_vector_gauss(float a1, float a2, float a3, float a4)
+{
+    a1 = (a1 < 1.0f) ? 1.0f : a1;                     // a zero draw counts as the smallest one
+    a3 = (a3 < 1.0f) ? 1.0f : a3;
+    const float r1 = sqrt_rn(__builtin_fabsf(-2.0f * log_raw(a1))), r2 = sqrt_rn(__builtin_fabsf(-2.0f * log_raw(a3)));
+    float c1, s1, c2, s2;
+    sincos2pi_raw(a2, c1, s1);
+    sincos2pi_raw(a4, c2, s2);
+    return normalize(v3(r1 * c1, r1 * s1, r2 * c2));
+}
+
 // randomOnHalfUnitShere, RayTracing.glsl:64-80.
 RT_DEV V3 hemisphere_glsl(V3 n, float a1, float a2)            // raw draws
 {
@@ -486,7 +522,7 @@ RT_DEV uint32_t quantise(float c)
 // SEM 1: rules of RayTracing.glsl:233-288.
 // GEO bits 0-1: 0 spheres and cubes only (the instance has no traversal and no queue code), 1 boxes and / or
 // triangles staged in LDS, 2 triangles and their tree read from the blob in global memory; bit 2: the scene holds cubes of the CPU tracer, dielectric
-// materials or a colour per triangle (kept out of the other instances, whose registers and issue slots they
+// materials or a colour per triangle, or the context asks for the reference's normalised-Gaussian sphere sampler (kept out of the other instances, whose registers and issue slots they
 // would cost: 12 % on the four-sphere scene); bit 3: draws come from the
 // shader's own random() instead of the counter hash.  MODE 0: render.  MODE 1: render and count work.  MODE 2:
 // follow one sample, record hit and material ids, leave the accumulator alone.
@@ -516,7 +552,8 @@ void trace_kernel(const TraceParams P,
     // The 64 x (samples) paths of a wave's 8x8 tile are one pool that its lanes draw from (shader rules, whose integer
     // sums take any order): see "pool" below.
     constexpr bool POOL = RT_POOL != 0 && SEM == 1 && !TRACE && (GEO & 3) != 0;
-    constexpr bool HAS_QUEUES = (GEO & 3) != 0, TRI_GLOBAL = (GEO & 3) == 2, SPREAD_BOXES = HAS_QUEUES, HAS_CUBE = SEM == 0 && (GEO & 4) != 0, HAS_GLASS = (GEO & 4) != 0, HAS_TCOL = (GEO & 4) != 0, RNG_GLSL = (GEO & 8) != 0;
+    constexpr bool HAS_QUEUES = (GEO & 3) != 0, TRI_GLOBAL = (GEO & 3) == 2, SPREAD_BOXES = HAS_QUEUES, HAS_CUBE = SEM == 0 && (GEO & 4) != 0, HAS_GLASS = (GEO & 4) != 0, HAS_TCOL = (GEO & 4) != 0, RNG_GLSL = (GEO & 8) != 0,
+                   HAS_GAUSS = SEM == 0 && (GEO & 4) != 0 && (GEO & 8) == 0;
     extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -1076,6 +1113,17 @@ void trace_kernel(const TraceParams P,
             draw_pair(key, ended ? 0u : bounce_pair(bounce), u1, u2);
         }
 
+        // randomUnitVector(): the direct sphere point, or — RT_FLAG_UNIT_GAUSS — the reference's normalised Gaussians,
+        // whose two further draws are the event's second pair (called after ++bounce: the event's first pair is
+        // 2*bounce - 1).
+        auto sphere_point = [&](float a1, float a2) -> V3 {
+            if (HAS_GAUSS && (P.flags & 4u) != 0u) {
+                float a3, a4;
+                draw_pair(key, 2u * bounce, a3, a4);
+                return unit_vector_gauss(a1, a2, a3, a4);
+            }
+            return unit_vector(a1, a2);
+        };
         if (ended) {
             o = camera_origin(sample, u1, u2);
             v = o - cam_pos;                                          // rayTracer.h:100 / glsl:297
@@ -1087,7 +1135,7 @@ void trace_kernel(const TraceParams P,
             thr = ta;                                                 // scene.h:56 (0.6*albedo, formed at upload), :79; glsl:241,246,275
             if (diffuse) {
                 if (SEM == 0) {
-                    v = madd(1.0001f, n, unit_vector(u1, u2));        // Lambertian::scatter, scene.h:51-58; utils.h:48-50
+                    v = madd(1.0001f, n, sphere_point(u1, u2));       // Lambertian::scatter, scene.h:51-58; utils.h:48-50
                 } else {
                     v = hemisphere_glsl(n, u1, u2);                   // glsl:240,274
                     raw_dir = true;
@@ -1108,7 +1156,7 @@ void trace_kernel(const TraceParams P,
             } else if (SEM == 0) {
                 // Metal::scatter, scene.h:73-81; reflect, utils.h:62-64
                 v = madd(-(2.0f * dot(n, d)), n, d);
-                if (fuzz != 0.0f) v = madd(fuzz, unit_vector(u1, u2), v);
+                if (fuzz != 0.0f) v = madd(fuzz, sphere_point(u1, u2), v);
                 raw_dir = (P.flags & 1u) != 0u;
                 if (!(dot(v, n) > 0.0f)) {
                     // absorbed: emit() = 0 (scene.h:80,83-85).  The path ends here after all;
@@ -1400,7 +1448,8 @@ hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams
     P.plan_entries = n_workgroups;
     const dim3 grid((4u * n_workgroups + P.group_waves - 1u) / P.group_waves);
     const size_t lds_bytes = ((size_t)P.scene.lds_words + (tri_mode ? lds_wave_words(P.group_waves, tri_mode == 2) : 0u)) * 16u;
-    const int geo = tri_mode | (((sem == 0 && P.scene.n_cube != 0) || P.scene.has_glass || P.scene.tcol_off != 0) ? 4 : 0) | (P.rng_mode ? 8 : 0);
+    const int geo = tri_mode | (((sem == 0 && P.scene.n_cube != 0) || P.scene.has_glass || P.scene.tcol_off != 0 || (P.flags & 4u) != 0u) ? 4 : 0) |
+                    (P.rng_mode ? 8 : 0);
 #define RT_CASE(S, G, M) if (sem == S && geo == G && mode == M) return launch_one<S, G, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm, tile_order, tile_cost)
 #define RT_CASES(S, G) RT_CASE(S, G, 0); RT_CASE(S, G, 1); RT_CASE(S, G, 2)
 #define RT_GEOS(S) RT_CASES(S, 0); RT_CASES(S, 1); RT_CASES(S, 2); RT_CASES(S, 4); RT_CASES(S, 5); RT_CASES(S, 6); \

@@ -114,6 +114,25 @@ def test_shader_random_stream(rta, orc, name, kw):
     assert (a != b).any() and abs(a[..., :3].mean() - b[..., :3].mean()) < 0.25 * b[..., :3].mean() + 1e-3
 
 
+@pytest.mark.parametrize("name", ["c4", "cpu_tracer"])
+def test_unit_vector_from_normalised_gaussians(rta, orc, name):
+    """RT_FLAG_UNIT_GAUSS: randomUnitVector() as src/utils.h:45 writes it — three normal deviates, normalised — for the
+    Lambertian and the fuzzy metal, four draws per event; bit for bit against the oracle's recipe of it."""
+    from ray_tracing_amd import _abi
+    if name == "c4":
+        cfg, grid_n = rta.scenes.config4(width=160, height=90, spp=12, max_depth=11), 0
+    else:
+        cfg, grid_n = rta.scenes.config_cpu_tracer(width=96, height=96), 5
+    cfg.flags |= _abi.FLAG_UNIT_GAUSS
+    st = check_config(rta, orc, cfg, trace_samples=(0, 3), grid_n=grid_n)
+    assert st["diffuse"] > 0 and st["specular"] > 0
+    # the flag is refused where the shader's rules or its generator are asked for
+    cam = rta.Camera(8, 8)
+    for kw in (dict(semantics=rta.SEM_GLSL), dict(semantics=rta.SEM_CPU, rng=1)):
+        with pytest.raises(rta.RtError):
+            rta.RayTracingComputeShader(cam, flags=_abi.FLAG_UNIT_GAUSS, **kw)
+
+
 def test_metal_unnormalized_flag(rta, orc):
     cfg = rta.scenes.config4(width=96, height=54, spp=8, max_depth=11)
     cfg.flags = rta.FLAG_METAL_UNNORMALIZED

@@ -84,6 +84,15 @@ def test_sincos2pi(orc):
     assert err < 6e-7
 
 
+def test_logarithm_recipe_of_the_gaussian_sampler(orc):
+    """orc_log_draw(k * 2^-24) against math.log: 6e-7 absolute over draws from the smallest to the largest."""
+    import math
+    ks = list(range(1, 4097)) + [2 ** j for j in range(12, 24)] + [2 ** j + 1 for j in range(12, 24)] + [2 ** 24 - 1, 2 ** 24 - 2, 11863283, 11863284]
+    worst = max(abs(orc.log_draw(k * 2.0 ** -24) - math.log(k * 2.0 ** -24)) for k in ks)
+    assert worst < 1e-6
+    assert orc.log_draw(0.5) == np.float32(-math.log(2.0))          # m = 1 exactly: e * ln 2
+
+
 def test_unit_vector_is_uniform_on_the_sphere(orc):
     rng = np.random.RandomState(1)
     u = (rng.randint(0, 1 << 24, (4000, 2)) / 2.0 ** 24).astype(np.float32)

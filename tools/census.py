@@ -48,8 +48,8 @@ PHASES = [
     ("kernel: sphere loop", "    while (alive) {", "        // The lanes still tracing, and this lane's place among them"),
     ("kernel: boxes / cubes / tree walk", "        // The lanes still tracing, and this lane's place among them", "        // ---- the surface"),
     ("kernel: surface (record, normal, material)", "        // ---- the surface", "        // Two draws per lane: the bounce's pair"),
-    ("kernel: accumulate + draws", "        // Two draws per lane: the bounce's pair", "        if (ended) {\n            o = camera_origin"),
-    ("kernel: restart / scatter", "        if (ended) {\n            o = camera_origin", "        // normalize(v), or v as it is"),
+    ("kernel: accumulate + draws", "        // Two draws per lane: the bounce's pair", "        // randomUnitVector(): the direct sphere point, or"),
+    ("kernel: restart / scatter", "        // randomUnitVector(): the direct sphere point, or", "        // normalize(v), or v as it is"),
     ("kernel: new direction", "        // normalize(v), or v as it is", "    if (!TRACE && valid) {\n        if (CAN_SLICE"),
     ("kernel: write-back", "    if (!TRACE && valid) {\n        if (CAN_SLICE", "// Turns the per-tile costs"),
 ]
