@@ -76,6 +76,52 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def live_counters(argv_config, timeout_s=90):
+    """Hardware counters of the dominant kernel, measured now: this same script, as a child of rocprofv3, once per
+    --pmc pass (the passes the MI355X guide prescribes: FETCH_SIZE and WRITE_SIZE apart, the SQ counters in a pass of
+    their own), each a few frames with one frame in flight and no one-shot frame.  Called before this process
+    touches the GPU.  -> per-launch averages over the render kernel's dispatches, or None when anything goes wrong
+    (no rocprofv3, a pass that fails or runs into its time limit): the line then falls back on the filed profile."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3")
+    if rocprof is None:
+        return None
+    passes = [["FETCH_SIZE", "GRBM_GUI_ACTIVE"], ["WRITE_SIZE"],
+              ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAVES", "SQ_LDS_IDX_ACTIVE"]]
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="rt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for i, counters in enumerate(passes):
+            d = os.path.join(tmp, f"p{i}")
+            cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--counters-child", "--steps", "3", "--warmup", "1", "--streams", "1", "--no-cpu-baseline", *argv_config]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            vals = {}
+            for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    name = row["Kernel_Name"]
+                    if re.search(r"trace_kernel<\d+, \d+, 0>", name):                     # MODE 0: the render kernel
+                        vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for k, v in vals.items():
+                v.sort()
+                med = v[len(v) // 2]
+                keep = [x for x in v if med == 0 or abs(x - med) <= 0.25 * abs(med)]
+                out[k] = sum(keep) / len(keep)
+        return out or None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cpu_baseline(cfg, target_seconds=12.0, gpu_render=None):
     """The CPU oracle (a restatement of the reference's tracer; the reference itself cannot be built
     here) timed on this host on a bounded sample of the same workload.  The frame it produces is
@@ -145,7 +191,18 @@ def main():
     ap.add_argument("--mesh", default="", help="c3 only: the mesh file under ray_tracing_amd/data (default Bunny-LowPoly.off; bunny.off has 4 968 triangles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="one GPU: frames in flight, each on its own context and stream (1: one after the other)")
+    ap.add_argument("--no-live-counters", action="store_true", help="do not run the rocprofv3 --pmc passes; roofline.traffic then comes from profiles/traffic.json")
+    ap.add_argument("--counters-child", action="store_true", help=argparse.SUPPRESS)   # this run is one of those passes
     args = ap.parse_args()
+
+    # One GPU: the dominant kernel's counters, measured in this run by three short rocprofv3 passes over this script
+    # (before this process touches the GPU).
+    live = None
+    if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.counters_child and not args.no_live_counters:
+        cfg_argv = ["--config", args.config] + (["--mesh", args.mesh] if args.mesh else []) + (["--spp", str(args.spp)] if args.spp else []) + \
+                   (["--width", str(args.width), "--height", str(args.height)] if args.width and args.height else []) + \
+                   (["--semantics", str(args.semantics)] if args.semantics >= 0 else [])
+        live = live_counters(cfg_argv)
 
     import torch
     import torch.distributed as dist
@@ -245,7 +302,7 @@ def main():
         # A one-shot call: a fresh context (no plan learned from an earlier frame), one render of the whole workload,
         # waited for.  The process has run the kernel before (the stats launch), so its code is loaded.
         cold_ms = None
-        if world == 1:
+        if world == 1 and not args.counters_child:
             rt_cold = rta.scenes.make_renderer(cfg, device=local_rank)
             rt_cold.setStream(streams[0].cuda_stream)
             accums[0].zero_()
@@ -337,6 +394,28 @@ def main():
                                      "conversions / integer multiplies in 4, sqrt / rcp in 8"}
             except Exception:
                 traffic, issue = None, None
+        if live and "FETCH_SIZE" in live and "WRITE_SIZE" in live:
+            # measured in this run: (2 * FETCH_SIZE + WRITE_SIZE) KB — on gfx950 FETCH_SIZE tallies the 128-byte requests
+            # of 16-byte-per-lane reads at 64 bytes
+            traffic = round((2.0 * live["FETCH_SIZE"] + live["WRITE_SIZE"]) * 1024.0)
+            traffic_note = {"source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, 3 frames each, "
+                                      "(2 * FETCH_SIZE + WRITE_SIZE) * 1024", "fetch_size_kb": round(live["FETCH_SIZE"], 1),
+                            "write_size_kb": round(live["WRITE_SIZE"], 1), "kernel_sha": kernel_source_sha(), "traffic_stale": False}
+        if live and live.get("SQ_INSTS_VALU"):
+            n_inst = live["SQ_INSTS_VALU"]
+            cyc = kernel_ms * 1e-3 * PEAK_CLOCK_HZ * N_SIMD / n_inst
+            lds_busy = None
+            if live.get("SQ_LDS_IDX_ACTIVE") and live.get("GRBM_GUI_ACTIVE"):
+                lds_busy = round(100.0 * live["SQ_LDS_IDX_ACTIVE"] / (live["GRBM_GUI_ACTIVE"] / 8.0 * 256.0), 1)
+            issue = {"valu_instructions_per_launch": round(n_inst), "cycles_per_instruction_per_simd": round(cyc, 3),
+                     "best_cycles_per_instruction": 2.0, "issue_slots_used": round(2.0 / cyc, 4),
+                     "lanes_enabled_percent": round(100.0 * live["SQ_THREAD_CYCLES_VALU"] / (64.0 * live["SQ_ACTIVE_INST_VALU"]), 1)
+                     if live.get("SQ_ACTIVE_INST_VALU") and live.get("SQ_THREAD_CYCLES_VALU") else None,
+                     "lds_busy_percent": lds_busy, "source": "measured in this run (rocprofv3 --pmc pass of the SQ counters)",
+                     "note": "1024 SIMDs at 2.4 GHz; a wave64 fp32 instruction issues in 2 cycles at best, compares / selects / "
+                             "conversions / integer multiplies in 4, sqrt / rcp in 8"}
+            if lds_busy is not None:
+                bound = "lds" if lds_busy / 100.0 > 2.0 / cyc else "valu"
         info = rta.device_info(local_rank)
         result = {
             "metric": "Msamples/sec at 1080p", "value": round(value, 2), "unit": "Msamples/s",
