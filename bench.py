@@ -198,7 +198,8 @@ def main():
     # One GPU: the dominant kernel's counters, measured in this run by three short rocprofv3 passes over this script
     # (before this process touches the GPU).
     live = None
-    if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.counters_child and not args.no_live_counters:
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)        # someone else's rocprofv3 is already watching this run
+    if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.counters_child and not args.no_live_counters and not under_profiler:
         cfg_argv = ["--config", args.config] + (["--mesh", args.mesh] if args.mesh else []) + (["--spp", str(args.spp)] if args.spp else []) + \
                    (["--width", str(args.width), "--height", str(args.height)] if args.width and args.height else []) + \
                    (["--semantics", str(args.semantics)] if args.semantics >= 0 else [])
