@@ -519,7 +519,17 @@ static int closest_hit(tracer* T, const ray* r, float* t_out)
 
 static v3 shape_normal(const orc_params* prm, const orc_shape* s, v3 p)
 {
-    if (s->type == 0) return normalize(vsub(p, shape_center(s)));      /* scene.h:130-132, glsl:134-136 */
+    if (s->type == 0) {                                               /* scene.h:130-132, glsl:134-136 */
+        v3 v = vsub(p, shape_center(s));
+        if (t_lit) return normalize(v);
+        /* The recipe: |v| is the radius to the rounding of the hit distance, so 1/radius is a first guess of
+         * 1/sqrt(v.v) that one Newton step y <- y (1.5 - (0.5 q y) y) takes to rounding level. */
+        float inv_r = 1.0f / s->m[0];
+        float q = dot(v, v);
+        float t = (0.5f * q) * inv_r;
+        float e = fmaf(-t, inv_r, 1.5f);
+        return vscale(v, inv_r * e);
+    }
     if (s->type == 1) {
         float c[3] = { s->m[12], s->m[13], s->m[14] }, pp[3] = { p.x, p.y, p.z }, n[3], sides[3];
         box_sides(prm, s, sides);

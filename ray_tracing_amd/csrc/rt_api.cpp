@@ -406,7 +406,7 @@ static int build_blob_impl(rt_ctx* ctx)
         as_u32(r1.f[3]) = (s.material.type & 0xffffu) | ((s.type & 0xffu) << 16) | (cls << 24);
         r2.f[0] = cls == 2u && ctx->cfg.semantics == RT_SEM_CPU ? s.material.data[1] : 0.0f;   // fuzz: the CPU tracer's metal only (scene.h:71,78)
         r2.f[1] = emit;
-        r2.f[2] = rcp_nr(scale);
+        r2.f[2] = s.type == RT_SHAPE_CIRCLE ? 1.0f / scale : rcp_nr(scale);      // sphere: first guess of its normal's 1 / length; box: boxNormalAt's 1 / side
         // A Box's sides along y and z: the shader's single side, or its own (RT_FLAG_BOX_SIDES).
         const bool own_sides = (ctx->cfg.flags & RT_FLAG_BOX_SIDES) != 0u;
         const float side_y = own_sides ? s.transformation[5] : scale, side_z = own_sides ? s.transformation[10] : scale;

@@ -20,7 +20,7 @@ namespace rtd {
 //                                   class: 0 the path ends here and returns throughput x colour x emit,
 //                                          1 Lambertian, 2 metal, 3 dielectric, 4 debug (returns the normal)
 //                           word 2: fuzz, emit (1: light, or unknown material under the shader's rules; else 0),
-//                                   rcp_nr(scale), place in cub (uint32; cubes only)
+//                                   1 / scale (Circle: IEEE quotient; Box: rcp_nr), place in cub (uint32; cubes only)
 //                           word 3: dielectric: 1/ior, Schlick's r0 = ((1-ior)/(1+ior))^2; box: 1/side y, 1/side z
 //                         the record behind the shapes' is all zero: class 0, emit 0, colour 0
 //   sph  [n_sph_pad]      spheres in upload order: centre.xyz, radius^2; padded to a

@@ -101,6 +101,17 @@ RT_DEV float rsqrt_nr(float q)
     return y;
 }
 RT_DEV V3 normalize(V3 v) { return v * rsqrt_nr(dot(v, v)); }
+// normalize(p - centre) at a point of a sphere (scene.h:130-132, RayTracing.glsl:134-136): the length is the radius
+// to the rounding of the hit distance (relative d, 1e-7 .. 1e-5), so 1/radius — stored with the shape — is a first
+// guess that ONE Newton step y <- y * (1.5 - (0.5 q y) y) takes to 1.5 d^2 of 1/sqrt(q): four instructions for the
+// thirteen of the bit-trick guess and its three steps.
+RT_DEV V3 sphere_normal(V3 v, float inv_radius)
+{
+    const float q = dot(v, v);
+    const float t = (0.5f * q) * inv_radius;
+    const float e = fma_(-t, inv_radius, 1.5f);
+    return v * (inv_radius * e);
+}
 // 1/x the same way: y <- y * (2 - x*y), three times (relative error <= 1.2e-7).
 // a / b of the shader's routines (RayTracing.glsl:145,161,181) is a * rcp_nr(b):
 // GLSL specifies its division to 2.5 ulp only, and the correctly rounded
@@ -1007,7 +1018,7 @@ void trace_kernel(const TraceParams P,
         float emit = r2.y, fuzz = r2.x, glass_eta = 0.0f, glass_r0 = 0.0f;
         // An instance without boxes, triangles and cubes is launched only for scenes in which every shape that can
         // be hit is a sphere.
-        if ((!HAS_QUEUES && !HAS_CUBE) || stype == 0u) n = normalize(v3(p.x - r0.x, p.y - r0.y, p.z - r0.z));      // scene.h:130-132
+        if ((!HAS_QUEUES && !HAS_CUBE) || stype == 0u) n = sphere_normal(v3(p.x - r0.x, p.y - r0.y, p.z - r0.z), r2.z);   // scene.h:130-132
         else if (HAS_QUEUES && stype == 1u) { const float4 r3 = rec[4u * rid + 3u]; n = box_normal(xyz(r0), r2.z, r3.z, r3.w, p); }
         else if (HAS_CUBE && stype == 3u) {
             // rotation^T * normalAt(inPoint), scene.h:150-164,196: the row of the rotation that
