@@ -487,16 +487,17 @@ RT_DEV void test_triangle(float4 w0, float4 w1, float4 w2, float4 w3, uint32_t n
 
 // Can the ray touch the bounding sphere nb = {centre.xyz, R}?  It does when its line passes
 // within R of the centre, (oc.d)^2 + R^2 >= |oc|^2 for a unit direction, and the sphere is not
-// behind the origin.  The rounding error of the two sides is a few 2^-24 of |oc|^2; the term
-// 1e-6 * |oc|^2 on the right covers it (and a direction that is unit only to 1e-6), R's own
-// slack covers the triangle test's.  A NaN centre never hits.
+// behind the origin.  A direction whose length is off by e shifts (oc.d)^2 by 2 e |oc|^2 — the shader's diffuse
+// direction is used as sampled, unit to about 1e-6 — and the rounding of the two dot products adds about 1e-6 of
+// |oc|^2 more: the term 4e-6 * |oc|^2 on the right covers both, R's own slack covers the triangle test's.  A NaN
+// centre never hits.
 template <int SEM>
 RT_DEV bool bound_hit(float4 nb, V3 o, V3 d, uint32_t best_key)
 {
     V3 oc = v3(o.x - nb.x, o.y - nb.y, o.z - nb.z);
     float b = dot(oc, d);
     float oc2 = dot(oc, oc);
-    float rhs = fma_(1e-6f, oc2, nb.w * nb.w);
+    float rhs = fma_(4e-6f, oc2, nb.w * nb.w);
     // Nothing inside the sphere is nearer along the ray than -(b + R): with a hit already nearer than that
     // (by more than the rounding of b), the sphere cannot hold the closest one.
     float lim = __uint_as_float(best_key + Window<SEM>::tmin) * -1.00001f;

@@ -524,6 +524,28 @@ def test_mesh_scene_without_culling(rta, orc):
     check_config(rta, orc, cfg)
 
 
+def test_bounds_are_conservative_for_far_grazing_rays(rta, orc):
+    """A long lens 300 units away: |origin - centre|^2 is 10^7 times a leaf's R^2, so whether a bounding ball is
+    touched is decided by the slack term of the bound test.  Culled and exhaustive walks (flag 1 switches the bounds
+    off; under the shader's rules it does nothing else) must give the same hits, and both the oracle's."""
+    from ray_tracing_amd import host
+    cfg = rta.scenes.config3(width=96, height=64, spp=6, max_depth=6)
+    cfg.camera = host.Camera(cfg.width, cfg.height, 60.0, (0.5, 0.9, 298.0)).data.copy()
+    frames, hits = [], []
+    for flags in (0, rta.FLAG_METAL_UNNORMALIZED):
+        cfg.flags = flags
+        st = check_config(rta, orc, cfg, trace_samples=(0, 4))
+        rt = rta.scenes.make_renderer(cfg)
+        rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed)
+        frames.append(rt.resolve(cfg.width, cfg.height).view(np.uint32).copy())
+        hits.append(rt.traceDebug(cfg.width, cfg.height, cfg.max_depth, cfg.seed, 1)[0])
+        rt.close()
+        assert st["triangle_tests_done"] > 0
+    np.testing.assert_array_equal(frames[0], frames[1])
+    np.testing.assert_array_equal(hits[0], hits[1])
+    assert (hits[0][..., 0] >= len(cfg.shapes)).mean() > 0.02          # the mesh is in view
+
+
 def test_many_boxes_fill_more_than_one_pass(rta, orc):
     """Forty boxes in view: the (lane, box) pairs of one ray segment exceed the 64 a pass takes."""
     from ray_tracing_amd import host
