@@ -236,7 +236,7 @@ int rt_bind_accum(rt_ctx* ctx, void* device_words, uint32_t width, uint32_t heig
  * Asynchronous on the context's stream.
  * Workgroups are handed tiles by a plan made from what the tiles cost in the previous call of the
  * same frame size; a call of 64 or more samples per pixel that has no plan yet makes one from its
- * own first 16 samples.  Any plan gives the same words. */
+ * own first 8 samples.  Any plan gives the same words. */
 int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp,
               uint32_t max_depth, uint64_t seed, uint32_t first_sample,
               uint32_t grid_n);

@@ -397,7 +397,7 @@ def test_sliced_sample_ranges(rta, orc):
             np.testing.assert_array_equal(img.view(np.uint32), ref.view(np.uint32))
             assert {k: st[k] for k in COUNTERS} == {k: ostats[k] for k in COUNTERS}
             units.append(st["work_units"])
-        # the first frame has no plan: it probes with its first 16 samples (one workgroup per tile), then runs the
+        # the first frame has no plan: it probes with its first 8 samples (one workgroup per tile), then runs the
         # rest by the plan made from them; later frames run by the plan of the frame before
         assert units[0] > 2 * n_tiles and units[1] > n_tiles and units[2] > n_tiles, units
         # two half frames on top of each other (the second one sliced too) = one frame
