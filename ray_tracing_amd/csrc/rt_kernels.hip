@@ -526,7 +526,11 @@ RT_DEV bool box_bound_hit(float4 c, float4 h, V3 o, V3 inv_d, uint32_t best_key)
 RT_DEV uint32_t quantise(float c)
 {
     float v = 255.0f * c;
-    return (v > 0.0f) ? ((v >= 4294967296.0f) ? 0xffffffffu : (uint32_t)v) : 0u;
+    // the instruction itself: C leaves the conversion of an out-of-range value undefined, so spelled in C the
+    // saturation costs two compares and two selects per channel on top of it
+    uint32_t q;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(q) : "v"(v));
+    return q;
 }
 
 // -------------------------------------------------------------- the tracer
