@@ -44,7 +44,13 @@ namespace rtd {
 // centre).  A node is {centre.xyz, R}, R = 1.01 * radius + 1e-4 (radius: of a small enclosing ball of the node's vertices): the slack covers the
 // rounding of the triangle test itself, so that a ray the triangle test could accept is
 // never culled (see bound_hit in rt_kernels.hip).
-constexpr uint32_t TREE_LEAF = 4, TREE_FAN = 8, TREE_LEVELS = 4;
+#ifndef RT_TREE_LEAF
+#define RT_TREE_LEAF 4
+#endif
+#ifndef RT_TREE_FAN
+#define RT_TREE_FAN 8
+#endif
+constexpr uint32_t TREE_LEAF = RT_TREE_LEAF, TREE_FAN = RT_TREE_FAN, TREE_LEVELS = 4;
 struct SceneLayout {
     uint32_t n_shapes, n_sph_pad, n_box, n_cube, n_tris;
     uint32_t rec_off, sph_off, sid_off, box_off, cub_off, inv_off, tri_off;   // in 16-byte words
@@ -106,7 +112,10 @@ constexpr uint32_t LDS_MAX_BYTES = 64u * 1024u;
 #define RT_SPREAD_BELOW 24
 #endif
 constexpr uint32_t QUEUE_ENTRIES = 128u, SPREAD_BELOW = RT_SPREAD_BELOW;
-constexpr uint32_t NODE_STACK_STAGED = 32u, NODE_STACK_GLOBAL = 256u;
+#ifndef RT_NODE_STACK_STAGED
+#define RT_NODE_STACK_STAGED 32u
+#endif
+constexpr uint32_t NODE_STACK_STAGED = RT_NODE_STACK_STAGED, NODE_STACK_GLOBAL = 256u;
 // What is left below a full pass, plus what one step can add, must fit (64 lanes; a pass takes 64 / TREE_LEAF pairs
 // or 64 / TREE_FAN triples and can put 64 new ones there; three levels above the leaves).
 static_assert(TREE_LEAF >= 1u && TREE_LEAF <= 64u && TREE_FAN >= 2u && TREE_FAN <= 64u && SPREAD_BELOW <= 64u, "tree shape");
