@@ -33,6 +33,8 @@ def main():
         shutil.copy(stats[0], os.path.join(HERE, name + "_kernel_stats.csv"))
     out = subprocess.run([sys.executable, os.path.join(HERE, "summarize.py"), run, needle], check=True, capture_output=True, text=True).stdout
     summary = json.loads(out)
+    if not stats or not summary.get("counters_per_launch"):
+        sys.exit(f"{run}: no kernel trace or no counters there; nothing filed")
     summary["kernel_source_sha"] = kernel_source_sha()
     json.dump(summary, open(os.path.join(HERE, name + "_summary.json"), "w"), indent=1)
     c, d = summary["counters_per_launch"], summary["derived"]

@@ -106,8 +106,8 @@ constexpr uint32_t LDS_MAX_BYTES = 64u * 1024u;
 // most 8 and 16 pairs).  That bounds them: a staged mesh queues only level-1 nodes, 7 left over + 23 new;  for a
 // mesh in global memory, whose nodes of all levels are queued, a pass takes 8 triples off the top and may put 64
 // children there, which the next pass takes first: 30 + 2 x 56 + 64 at most (three levels above the leaves).
-// (Measured on the 292-triangle mesh scene: thresholds of 16, 24 and 40 lanes give the same 20.0 ms, 57 gives
-// 21.5, queueing always 23.3.)
+// (Measured on the 292-triangle mesh scene: thresholds of 8, 16, 24 and 40 lanes give 14.9, 14.7, 14.7 and 14.9 ms,
+// on the 4 968-triangle one 18.9, 18.3, 18.3 and 18.7.)
 #ifndef RT_SPREAD_BELOW
 #define RT_SPREAD_BELOW 24
 #endif
