@@ -522,6 +522,9 @@ static v3 shape_normal(const orc_params* prm, const orc_shape* s, v3 p)
     if (s->type == 0) {                                               /* scene.h:130-132, glsl:134-136 */
         v3 v = vsub(p, shape_center(s));
         if (t_lit) return normalize(v);
+        /* A fuzzy metal's direction left as written (scene.h:78) is not unit, and Sphere::hit, which assumes it is
+         * (scene.h:115-123), then returns a point off the sphere: |v| is not the radius there. */
+        if (prm->semantics == ORC_SEM_CPU && (prm->flags & ORC_FLAG_METAL_UNNORMALIZED)) return normalize(v);
         /* The recipe: |v| is the radius to the rounding of the hit distance, so 1/radius is a first guess of
          * 1/sqrt(v.v) that one Newton step y <- y (1.5 - (0.5 q y) y) takes to rounding level. */
         float inv_r = 1.0f / s->m[0];

@@ -930,7 +930,7 @@ void trace_kernel(const TraceParams P,
                 const uint32_t n_children = level == 1u ? L.node_n[0] : (level == 2u ? L.node_n[1] : L.node_n[2]);
                 const uint32_t children_at = level == 1u ? L.node_off[0] : (level == 2u ? L.node_off[1] : L.node_off[2]);
                 const bool valid = work && child < n_children;
-                const bool touch = valid && bound_hit<SEM>(nodes[children_at + (valid ? child : 0u)], ro, rd, rkey);
+                const bool touch = valid && (!cull || bound_hit<SEM>(nodes[children_at + (valid ? child : 0u)], ro, rd, rkey));
                 if (STATS && valid) ++n_node;
                 if (DEEP) push_nodes(touch && level != 1u, src, level - 1u, child);
                 RT_PHASE_MARK3(2)
@@ -1023,7 +1023,14 @@ void trace_kernel(const TraceParams P,
         float emit = r2.y, fuzz = r2.x, glass_eta = 0.0f, glass_r0 = 0.0f;
         // An instance without boxes, triangles and cubes is launched only for scenes in which every shape that can
         // be hit is a sphere.
-        if ((!HAS_QUEUES && !HAS_CUBE) || stype == 0u) n = sphere_normal(v3(p.x - r0.x, p.y - r0.y, p.z - r0.z), r2.z);   // scene.h:130-132
+        if ((!HAS_QUEUES && !HAS_CUBE) || stype == 0u) {
+            const V3 pc_ = v3(p.x - r0.x, p.y - r0.y, p.z - r0.z);
+            n = sphere_normal(pc_, r2.z);                             // scene.h:130-132
+            // A fuzzy metal's direction left as written is not unit, and the sphere test, which assumes it is, then
+            // returns a point off the sphere: the radius is no first guess of that length.  (A branch on the launch's
+            // flags; the empty statement keeps it one.)
+            if (SEM == 0 && !cull) { asm volatile(""); n = normalize(pc_); }
+        }
         else if (HAS_QUEUES && stype == 1u) { const float4 r3 = rec[4u * rid + 3u]; n = box_normal(xyz(r0), r2.z, r3.z, r3.w, p); }
         else if (HAS_CUBE && stype == 3u) {
             // rotation^T * normalAt(inPoint), scene.h:150-164,196: the row of the rotation that

@@ -1,0 +1,173 @@
+"""A randomised parity campaign: many small random scenes, every one rendered by the HIP path (through the C ABI)
+and by the CPU oracle and compared word for word — work counters, every accumulated image word, and the hit and
+material ids of one followed sample.  Wider than tests/test_gpu_parity.py::test_random_scenes: both rule sets, all
+sample modes, both draw streams, the flags, cubes, dielectrics, debug and unknown materials, boxes with their own
+sides, triangle colours, meshes from none to a few thousand triangles (staged in LDS or read from global memory),
+cameras inside and outside the scene, ragged frame sizes, depths 1 .. 9.
+
+    python tools/parity_campaign.py [n_scenes] [first_seed]       # needs an MI355X; prints one line per failure
+
+The oracle is the checker here, never the thing measured."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import ray_tracing_amd as rta
+from ray_tracing_amd import _abi, host
+from oracle import oracle as orc
+
+COUNTERS = ("samples", "segments", "diffuse", "specular", "terminal",
+            "shape_tests", "sphere_tests", "box_tests", "triangle_tests")
+
+
+def random_config(seed):
+    rng = np.random.default_rng(77000 + seed)
+    sem = int(rng.integers(0, 2))
+    flags = 0
+    if sem == 0 and rng.random() < 0.25:
+        flags |= _abi.FLAG_METAL_UNNORMALIZED
+    if rng.random() < 0.3:
+        flags |= _abi.FLAG_BOX_SIDES
+    rng_mode = _abi.RNG_GLSL if rng.random() < 0.2 else _abi.RNG_HASH
+    if sem == 0 and rng_mode == _abi.RNG_HASH and rng.random() < 0.2:
+        flags |= _abi.FLAG_UNIT_GAUSS
+    mode = int(rng.choice([_abi.SAMPLE_JITTER, _abi.SAMPLE_JITTER, _abi.SAMPLE_GRID, _abi.SAMPLE_GRID_COMPAT]))
+    grid_n = int(rng.integers(1, 4)) if mode != _abi.SAMPLE_JITTER else 0
+    spp = grid_n * grid_n if grid_n else int(rng.integers(1, 7))
+
+    def colour(lo=0.2, hi=1.0):
+        return tuple(float(x) for x in rng.uniform(lo, hi, 3))
+
+    def material():
+        kind = int(rng.integers(0, 10))
+        if kind == 0:
+            return host.Light(colour(1.0, 4.0))
+        if kind in (1, 2):
+            return host.Metal(colour(), fuzz=float(rng.choice([0.0, 0.0, 0.15, 0.6]))) if sem == 0 else host.Metal(colour())
+        if kind == 3:
+            return host.Dielectric(colour(0.7, 1.0), ior=float(rng.uniform(1.1, 2.0)))
+        if kind == 4 and rng.random() < 0.5:
+            return host.DebugMaterial(colour())
+        return host.Lambertian(colour())
+
+    spread = float(rng.choice([1.0, 1.0, 3.0, 30.0]))
+
+    def point():
+        return (float(rng.uniform(-3, 5) * spread), float(rng.uniform(0, 4) * spread), float(rng.uniform(-9, -1) * spread))
+
+    objs = []
+    if rng.random() < 0.7:
+        objs.append(host.Box((0, -50, 0), (100, 1, 1), host.Lambertian(colour())))
+    if rng.random() < 0.8:
+        objs.append(host.Circle((1, 7 * spread, -4), 2.5 * spread, host.Light((3, 3, 3))))
+    n_sph = int(rng.choice([0, 1, 3, 4, 5, 8, 13, 40]))
+    n_box = int(rng.choice([0, 0, 1, 3, 7, 20]))
+    n_cube = int(rng.choice([0, 0, 1, 2])) if sem == 0 else 0
+    for _ in range(n_sph):
+        objs.append(host.Circle(point(), float(rng.uniform(0.2, 1.0) * spread), material()))
+    for _ in range(n_box):
+        sides = tuple(float(x) for x in rng.uniform(0.3, 1.5, 3) * spread) if rng.random() < 0.5 else (float(rng.uniform(0.3, 1.5) * spread),) * 3
+        objs.append(host.Box(point(), sides, material()))
+    for _ in range(n_cube):
+        c = host.Cube(point(), material())
+        c.rotate(float(rng.uniform(-3, 3)))
+        objs.append(c)
+    rng.shuffle(objs)
+    shapes = host.pack(objs, _abi.SHAPE_DTYPE) if objs else np.zeros(0, dtype=_abi.SHAPE_DTYPE)
+    if len(shapes) and rng.random() < 0.1:
+        shapes = shapes.copy()
+        shapes["material"]["type"][int(rng.integers(0, len(shapes)))] = 55          # a material type the shader does not know
+
+    n_tris = int(rng.choice([0, 0, 1, 3, 5, 37, 150, 292, 700, 2500]))
+    tris = []
+    size = float(rng.choice([0.1, 0.6, 2.0])) * spread
+    for _ in range(n_tris):
+        a = np.array(point())
+        e1, e2 = rng.uniform(-size, size, 3), rng.uniform(-size, size, 3)
+        if rng.random() < 0.02:
+            e2 = e1 * float(rng.uniform(-2, 2))                                      # a degenerate one
+        tris.append(host.SimpleTriangle(tuple(a), tuple(a + e1), tuple(a + e2)))
+    triangles = host.pack(tris, _abi.TRIANGLE_DTYPE) if tris else np.zeros(0, dtype=_abi.TRIANGLE_DTYPE)
+    tcol = rng.uniform(0.1, 1.0, (n_tris, 3)).astype(np.float32) if n_tris and rng.random() < 0.3 else None
+
+    w, h = int(rng.integers(1, 120)), int(rng.integers(1, 70))
+    cam_pos = (1.0, 1.0, 6.0) if rng.random() < 0.6 else tuple(float(x) for x in np.array(point()) * rng.choice([1.0, 0.2]))
+    cam = host.Camera(w, h, float(rng.choice([1.0, 0.5, 2.0])), cam_pos)
+    if rng.random() < 0.3:
+        cam.rotate(float(rng.uniform(-0.8, 0.8)), float(rng.uniform(-0.4, 0.4)))
+    cfg = rta.scenes.SceneConfig(f"campaign{seed}", shapes, triangles, cam.data.copy(), w, h, spp, int(rng.integers(1, 10)), sem,
+                                 seed=int(rng.integers(0, 2 ** 40)), sample_mode=mode, flags=flags,
+                                 triangle_albedo=colour(), rng=rng_mode, triangle_colors=tcol)
+    stage = bool(n_tris and n_tris <= 300 and rng.random() < 0.4)
+    return cfg, grid_n, stage
+
+
+def run_one(seed):
+    cfg, grid_n, stage = random_config(seed)
+    if stage:
+        os.environ["RT_MESH_IN_LDS"] = "1"
+    else:
+        os.environ.pop("RT_MESH_IN_LDS", None)
+    rt = rta.scenes.make_renderer(cfg)
+    problems = []
+    try:
+        stats = rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, grid_n=grid_n, stats=True)
+        img = rt.resolve(cfg.width, cfg.height, gamma_sqrt=(cfg.semantics == 0))
+        p = orc.params(cfg.width, cfg.height, cfg.spp, cfg.max_depth, seed=cfg.seed, semantics=cfg.semantics,
+                       sample_mode=cfg.sample_mode, flags=cfg.flags, triangle_albedo=cfg.triangle_albedo, rng=cfg.rng,
+                       triangle_colors=cfg.triangle_colors, grid_n=grid_n)
+        acc, ostats = orc.render(cfg.shapes, cfg.triangles, cfg.camera, p)
+        ref = orc.resolve(acc, cfg.spp, cfg.semantics, gamma_sqrt=(cfg.semantics == 0))
+        bad = [k for k in COUNTERS if stats[k] != ostats[k]]
+        if bad:
+            problems.append("counters " + ", ".join(f"{k} {stats[k]} != {ostats[k]}" for k in bad))
+        diff = img.view(np.uint32) != ref.view(np.uint32)
+        if diff.any():
+            problems.append(f"{int(diff.sum())} of {diff.size} image words")
+        s = cfg.spp - 1
+        hit, mat = rt.traceDebug(cfg.width, cfg.height, cfg.max_depth, cfg.seed, s, grid_n=grid_n)
+        ohit, omat = orc.trace(cfg.shapes, cfg.triangles, cfg.camera, p, s)
+        if not np.array_equal(hit, ohit):
+            problems.append(f"{int((hit != ohit).sum())} hit ids of sample {s}")
+        if not np.array_equal(mat, omat):
+            problems.append(f"{int((mat != omat).sum())} material ids of sample {s}")
+        # the plain render (no counters; the pooled instance under the shader's rules) gives the same words
+        rt.resetAccum()
+        rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, grid_n=grid_n)
+        img2 = rt.resolve(cfg.width, cfg.height, gamma_sqrt=(cfg.semantics == 0))
+        if not np.array_equal(img2.view(np.uint32), ref.view(np.uint32)):
+            problems.append(f"{int((img2.view(np.uint32) != ref.view(np.uint32)).sum())} image words of the plain render")
+    finally:
+        rt.close()
+    return cfg, stats, problems
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    t0 = time.time()
+    failed = 0
+    tot = dict(samples=0, segments=0, scenes=0, with_tris=0, with_boxes=0, sem0=0)
+    for seed in range(first, first + n):
+        cfg, stats, problems = run_one(seed)
+        tot["scenes"] += 1
+        tot["samples"] += stats["samples"]; tot["segments"] += stats["segments"]
+        tot["with_tris"] += 1 if len(cfg.triangles) else 0
+        tot["with_boxes"] += 1 if (cfg.shapes["type"] == 1).any() else 0
+        tot["sem0"] += 1 if cfg.semantics == 0 else 0
+        if problems:
+            failed += 1
+            print(f"FAIL seed {seed}: {cfg.width}x{cfg.height} spp {cfg.spp} depth {cfg.max_depth} sem {cfg.semantics} mode {cfg.sample_mode} "
+                  f"flags {cfg.flags} rng {cfg.rng} shapes {len(cfg.shapes)} tris {len(cfg.triangles)}: " + "; ".join(problems), flush=True)
+        if (seed - first + 1) % 25 == 0:
+            print(f"... {seed - first + 1} scenes, {failed} failed, {time.time() - t0:.0f} s", flush=True)
+    print(f"{tot['scenes']} random scenes (seeds {first} .. {first + n - 1}; {tot['sem0']} under the CPU tracer's rules, {tot['with_tris']} with "
+          f"triangles, {tot['with_boxes']} with boxes), {tot['samples']} samples, {tot['segments']} segments: {failed} differ from the oracle")
+    return 1 if failed else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
