@@ -5,7 +5,10 @@ sample modes, both draw streams, the flags, cubes, dielectrics, debug and unknow
 sides, triangle colours, meshes from none to a few thousand triangles (staged in LDS or read from global memory),
 cameras inside and outside the scene, ragged frame sizes, depths 1 .. 9.
 
-    python tools/parity_campaign.py [n_scenes] [first_seed]       # needs an MI355X; prints one line per failure
+    python tools/parity_campaign.py [--calls] [n_scenes] [first_seed]       # needs an MI355X; prints one line per failure
+
+With --calls every scene (64 .. 100 samples per pixel) goes through every way of calling the renderer instead (see
+run_calls) and the accumulators are compared.
 
 The oracle is the checker here, never the thing measured."""
 import os
@@ -145,14 +148,80 @@ def run_one(seed):
     return cfg, stats, problems
 
 
+def run_calls(seed):
+    """The same scene through every way of calling the renderer, each compared with the oracle's accumulator word for
+    word: a fresh context's one-shot call of 64+ samples (probe, plan, slices under the shader's rules), the same call
+    again (now by the plan of the first), the samples in three calls, the rows in shards of random band height, and the
+    call that allocates nothing."""
+    import torch
+    cfg, _, stage = random_config(seed)
+    rng = np.random.default_rng(991000 + seed)
+    cfg.sample_mode = _abi.SAMPLE_JITTER
+    cfg.spp = int(rng.integers(64, 101))
+    cfg.max_depth = min(cfg.max_depth, 6)
+    cfg.width, cfg.height = int(rng.integers(1, 73)), int(rng.integers(1, 49))
+    cam = host.Camera(cfg.width, cfg.height, 1.0, tuple(float(x) for x in cfg.camera[0:3]))
+    cfg.camera = cam.data.copy()
+    if len(cfg.triangles) > 300:
+        cfg.triangles = cfg.triangles[:300]
+        cfg.triangle_colors = None if cfg.triangle_colors is None else cfg.triangle_colors[:300]
+    if stage:
+        os.environ["RT_MESH_IN_LDS"] = "1"
+    else:
+        os.environ.pop("RT_MESH_IN_LDS", None)
+    w, h, spp, depth = cfg.width, cfg.height, cfg.spp, cfg.max_depth
+    p = orc.params(w, h, spp, depth, seed=cfg.seed, semantics=cfg.semantics, sample_mode=cfg.sample_mode, flags=cfg.flags,
+                   triangle_albedo=cfg.triangle_albedo, rng=cfg.rng, triangle_colors=cfg.triangle_colors)
+    acc, ostats = orc.render(cfg.shapes, cfg.triangles, cfg.camera, p)
+    ref = np.ascontiguousarray(acc).view(np.uint32).reshape(h, w, 4)[..., :3]
+    problems = []
+    buf = torch.zeros(h, w, 4, dtype=torch.int32, device="cuda")
+
+    def check(what):
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy().view(np.uint32)[..., :3]
+        if not np.array_equal(got, ref):
+            problems.append(f"{what}: {int((got != ref).sum())} of {ref.size} accumulator words")
+        buf.zero_()
+        torch.cuda.synchronize()
+
+    rt = rta.scenes.make_renderer(cfg)
+    try:
+        rt.bindAccum(buf.data_ptr(), w, h)
+        rt.render(w, h, spp, depth, cfg.seed)
+        check("one-shot call of a fresh context")
+        rt.render(w, h, spp, depth, cfg.seed)
+        check("the same call by the first one's plan")
+        a = int(rng.integers(1, spp - 1)); b = int(rng.integers(a + 1, spp))
+        for first, n in ((0, a), (a, b - a), (b, spp - b)):
+            rt.render(w, h, n, depth, cfg.seed, first_sample=first)
+        check(f"three calls ({a}, {b - a}, {spp - b} samples)")
+        shards, band = int(rng.integers(2, 5)), int(rng.choice([1, 3, 8, 16, 40]))
+        for g in range(shards):
+            rt.setRowShard(g, shards, band)
+            rt.render(w, h, spp, depth, cfg.seed)
+        rt.setRowShard(0, 1, 16)
+        check(f"{shards} row shards of {band}-row bands")
+        rt.renderNoAlloc(buf.data_ptr(), w, h, spp, depth, cfg.seed)
+        check("the call that allocates nothing")
+        rt.bindAccum(None, 0, 0)
+    finally:
+        rt.close()
+        os.environ.pop("RT_MESH_IN_LDS", None)
+    return cfg, ostats, problems
+
+
 def main():
+    calls = "--calls" in sys.argv
+    if calls:
+        sys.argv.remove("--calls")
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     t0 = time.time()
     failed = 0
     tot = dict(samples=0, segments=0, scenes=0, with_tris=0, with_boxes=0, sem0=0)
     for seed in range(first, first + n):
-        cfg, stats, problems = run_one(seed)
+        cfg, stats, problems = run_calls(seed) if calls else run_one(seed)
         tot["scenes"] += 1
         tot["samples"] += stats["samples"]; tot["segments"] += stats["segments"]
         tot["with_tris"] += 1 if len(cfg.triangles) else 0
@@ -164,7 +233,7 @@ def main():
                   f"flags {cfg.flags} rng {cfg.rng} shapes {len(cfg.shapes)} tris {len(cfg.triangles)}: " + "; ".join(problems), flush=True)
         if (seed - first + 1) % 25 == 0:
             print(f"... {seed - first + 1} scenes, {failed} failed, {time.time() - t0:.0f} s", flush=True)
-    print(f"{tot['scenes']} random scenes (seeds {first} .. {first + n - 1}; {tot['sem0']} under the CPU tracer's rules, {tot['with_tris']} with "
+    print(("every way of calling the renderer: " if calls else "") + f"{tot['scenes']} random scenes (seeds {first} .. {first + n - 1}; {tot['sem0']} under the CPU tracer's rules, {tot['with_tris']} with "
           f"triangles, {tot['with_boxes']} with boxes), {tot['samples']} samples, {tot['segments']} segments: {failed} differ from the oracle")
     return 1 if failed else 0
 
