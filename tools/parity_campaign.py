@@ -105,7 +105,42 @@ def random_config(seed):
                                  seed=int(rng.integers(0, 2 ** 40)), sample_mode=mode, flags=flags,
                                  triangle_albedo=colour(), rng=rng_mode, triangle_colors=tcol)
     stage = bool(n_tris and n_tris <= 300 and rng.random() < 0.4)
+    if seed >= EXTENDED_FROM:
+        extend(cfg, np.random.default_rng(55000 + seed))
     return cfg, grid_n, stage
+
+
+EXTENDED_FROM = 100000      # seeds from here on also get what extend() adds (earlier seeds keep their scenes)
+
+
+def extend(cfg, r):
+    """Ties and edges: copies of shapes and triangles with another colour somewhere else in the arrays (equal
+    distances: the first in upload order must win), shapes that touch or contain the camera, 64-bit seeds, a first
+    sample far into the stream, an occasional long path."""
+    if len(cfg.shapes) and r.random() < 0.6:
+        for _ in range(int(r.integers(1, 4))):
+            dup = cfg.shapes[int(r.integers(0, len(cfg.shapes)))].copy()
+            dup["material"]["color"] = r.uniform(0.1, 1.0, 3).astype(np.float32)
+            if r.random() < 0.3:
+                dup["material"]["type"] = int(r.choice([0, 1, 2]))
+            cfg.shapes = np.insert(cfg.shapes, int(r.integers(0, len(cfg.shapes) + 1)), dup)
+    if len(cfg.triangles) and r.random() < 0.5:
+        for _ in range(int(r.integers(1, 6))):
+            at, src = int(r.integers(0, len(cfg.triangles) + 1)), int(r.integers(0, len(cfg.triangles)))
+            cfg.triangles = np.insert(cfg.triangles, at, cfg.triangles[src].copy())
+            if cfg.triangle_colors is not None:
+                cfg.triangle_colors = np.insert(cfg.triangle_colors, at, r.uniform(0.1, 1.0, 3).astype(np.float32), axis=0)
+    if r.random() < 0.15:                                     # a sphere around the camera, or one it sits on
+        pos = cfg.camera[0:3].astype(np.float64)
+        radius = float(r.choice([0.5, 3.0, 40.0]))
+        centre = pos if r.random() < 0.5 else pos + np.array([radius, 0, 0])
+        extra = host.pack([host.Circle(tuple(centre), radius, host.Lambertian((0.6, 0.6, 0.6)))], _abi.SHAPE_DTYPE)
+        cfg.shapes = np.concatenate([cfg.shapes, extra]) if len(cfg.shapes) else extra
+    cfg.seed = int(r.integers(0, 2 ** 64, dtype=np.uint64))
+    if cfg.sample_mode == _abi.SAMPLE_JITTER and r.random() < 0.5:
+        cfg.notes["first_sample"] = int(r.choice([1, 99, 2 ** 24 - 3, 2 ** 31 + 5, 2 ** 32 - 1 - cfg.spp]))
+    if r.random() < 0.05:
+        cfg.max_depth = int(r.choice([33, 64]))
 
 
 def run_one(seed):
@@ -117,11 +152,12 @@ def run_one(seed):
     rt = rta.scenes.make_renderer(cfg)
     problems = []
     try:
-        stats = rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, grid_n=grid_n, stats=True)
+        first = cfg.notes.get("first_sample", 0)
+        stats = rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, first_sample=first, grid_n=grid_n, stats=True)
         img = rt.resolve(cfg.width, cfg.height, gamma_sqrt=(cfg.semantics == 0))
         p = orc.params(cfg.width, cfg.height, cfg.spp, cfg.max_depth, seed=cfg.seed, semantics=cfg.semantics,
                        sample_mode=cfg.sample_mode, flags=cfg.flags, triangle_albedo=cfg.triangle_albedo, rng=cfg.rng,
-                       triangle_colors=cfg.triangle_colors, grid_n=grid_n)
+                       triangle_colors=cfg.triangle_colors, grid_n=grid_n, first_sample=first)
         acc, ostats = orc.render(cfg.shapes, cfg.triangles, cfg.camera, p)
         ref = orc.resolve(acc, cfg.spp, cfg.semantics, gamma_sqrt=(cfg.semantics == 0))
         bad = [k for k in COUNTERS if stats[k] != ostats[k]]
@@ -130,7 +166,7 @@ def run_one(seed):
         diff = img.view(np.uint32) != ref.view(np.uint32)
         if diff.any():
             problems.append(f"{int(diff.sum())} of {diff.size} image words")
-        s = cfg.spp - 1
+        s = first + cfg.spp - 1
         hit, mat = rt.traceDebug(cfg.width, cfg.height, cfg.max_depth, cfg.seed, s, grid_n=grid_n)
         ohit, omat = orc.trace(cfg.shapes, cfg.triangles, cfg.camera, p, s)
         if not np.array_equal(hit, ohit):
@@ -139,7 +175,7 @@ def run_one(seed):
             problems.append(f"{int((mat != omat).sum())} material ids of sample {s}")
         # the plain render (no counters; the pooled instance under the shader's rules) gives the same words
         rt.resetAccum()
-        rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, grid_n=grid_n)
+        rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, first_sample=first, grid_n=grid_n)
         img2 = rt.resolve(cfg.width, cfg.height, gamma_sqrt=(cfg.semantics == 0))
         if not np.array_equal(img2.view(np.uint32), ref.view(np.uint32)):
             problems.append(f"{int((img2.view(np.uint32) != ref.view(np.uint32)).sum())} image words of the plain render")
