@@ -187,8 +187,8 @@ def run_one(seed):
 def run_calls(seed):
     """The same scene through every way of calling the renderer, each compared with the oracle's accumulator word for
     word: a fresh context's one-shot call of 64+ samples (probe, plan, slices under the shader's rules), the same call
-    again (now by the plan of the first), the samples in three calls, the rows in shards of random band height, and the
-    call that allocates nothing."""
+    again (now by the plan of the first), the samples in three calls, the rows in shards of random band height, the
+    call that allocates nothing; then three frames through the running-mean converter against the oracle's."""
     import torch
     cfg, _, stage = random_config(seed)
     rng = np.random.default_rng(991000 + seed)
@@ -241,6 +241,21 @@ def run_calls(seed):
         rt.renderNoAlloc(buf.data_ptr(), w, h, spp, depth, cfg.seed)
         check("the call that allocates nothing")
         rt.bindAccum(None, 0, 0)
+        # main.cpp:135-151: three frames through the running-mean converter, against the oracle's PixelConversion
+        k = int(rng.integers(1, 6))
+        rt.samples_per_frame = k
+        image = np.zeros((h, w, 4), np.float32)
+        for n in (1, 2, 3):
+            rt.updateCameraBuffer()
+            rt.compute(w, h, 1)
+            rt.convert(n)
+            pk = orc.params(w, h, k, depth, seed=cfg.seed, semantics=cfg.semantics, sample_mode=cfg.sample_mode, flags=cfg.flags,
+                            triangle_albedo=cfg.triangle_albedo, rng=cfg.rng, triangle_colors=cfg.triangle_colors, first_sample=(n - 1) * k)
+            acc_k, _ = orc.render(cfg.shapes, cfg.triangles, cfg.camera, pk)
+            orc.convert(acc_k, image, k, cfg.semantics, n)
+        got = rt.readImage()
+        if not np.array_equal(got.view(np.uint32), image.view(np.uint32)):
+            problems.append(f"running-mean converter, 3 frames of {k}: {int((got.view(np.uint32) != image.view(np.uint32)).sum())} image words")
     finally:
         rt.close()
         os.environ.pop("RT_MESH_IN_LDS", None)
