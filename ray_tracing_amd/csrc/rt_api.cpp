@@ -348,8 +348,8 @@ static int plan_blob(rt_ctx* ctx, BlobPlan& B)
     L.total_words = L.inv_off + (n_tris + 3u) / 4u;
     B.colors = !ctx->tri_colors.empty() && ctx->tri_colors.size() == 3u * (size_t)n_tris;
     const uint32_t wave_words = (n_tris || n_box) ? rtd::lds_wave_words(ctx->group_waves, false) : 0u;     // queues and slots of the spread tests
-    if ((size_t)(L.node_off[rtd::TREE_LEVELS - 1u] + (n_tris ? rtd::lds_wave_words(ctx->group_waves, true) : wave_words)) * 16u > rtd::LDS_MAX_BYTES)
-        return fail(ctx, RT_ERR_INVALID_ARG, "scene: %u shapes need more than the %u-byte LDS stage", n_shapes, rtd::LDS_MAX_BYTES);
+    if ((size_t)(L.node_off[rtd::TREE_LEVELS - 1u] + (n_tris ? rtd::lds_wave_words(ctx->group_waves, true) : wave_words)) * 16u > rtd::LDS_WORKGROUP_MAX_BYTES)
+        return fail(ctx, RT_ERR_INVALID_ARG, "scene: %u shapes need more than the %u bytes of LDS a workgroup can have", n_shapes, rtd::LDS_WORKGROUP_MAX_BYTES);
     if ((size_t)(staged_words + wave_words) * 16u <= rtd::LDS_MAX_BYTES && ctx->env_mesh_in_lds) { L.lds_words = staged_words; L.tri_in_lds = 1; }
     else { L.lds_words = L.node_off[rtd::TREE_LEVELS - 1u]; L.tri_in_lds = 0; }     // the mesh and its tree stay in global memory
     // Per-triangle albedo: read only at a hit, so it stays in global memory behind everything else.

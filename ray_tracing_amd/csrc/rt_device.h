@@ -99,6 +99,9 @@ constexpr uint32_t MAX_GROUP_WAVES = 8;   // instances with queues may be launch
 // triangles and their tree stay in global memory.
 constexpr uint32_t LDS_FULL_OCCUPANCY_BYTES = 20u * 1024u;
 constexpr uint32_t LDS_MAX_BYTES = 64u * 1024u;
+// The shapes are always staged: a scene may take what one workgroup can have of a CU's LDS (one workgroup per CU then;
+// about 1 800 spheres).  The runtime takes such a launch as it is (hipDeviceProp_t::sharedMemPerBlock is 160 KiB here).
+constexpr uint32_t LDS_WORKGROUP_MAX_BYTES = 160u * 1024u;
 // With boxes or triangles in the scene every wave of a workgroup owns, behind the staged scene, a queue of
 // (lane, leaf) pairs (QUEUE_ENTRIES x 4 bytes), one 8-byte slot per lane for the closest hit found, and a stack of
 // (lane, level, node) triples.  A node is put there only while fewer than SPREAD_BELOW lanes touch it (more: the

@@ -600,6 +600,32 @@ def test_random_scenes(rta, orc, seed):
     check_config(rta, orc, cfg, trace_samples=(0, 2))
 
 
+@pytest.mark.parametrize("sem", [0, 1])
+def test_many_hundred_shapes(rta, orc, sem):
+    """The shapes are staged in LDS whatever their number: 1 200 spheres and 250 boxes take 140 KiB of a workgroup's
+    160; twice as many are refused with a message, not launched."""
+    from ray_tracing_amd import host, _abi
+    rng = np.random.default_rng(5 + sem)
+
+    def many(n_sph, n_box):
+        objs = [host.Circle((1, 60, -4), 20.0, host.Light((3, 3, 3)))]
+        for _ in range(n_sph):
+            objs.append(host.Circle(tuple(float(x) for x in rng.uniform(-20, 20, 3) + (0, 0, -30)), float(rng.uniform(0.3, 1.5)),
+                                    host.Lambertian(tuple(float(x) for x in rng.uniform(0.2, 1, 3))) if rng.random() < 0.7 else host.Metal((0.9, 0.9, 0.9))))
+        for _ in range(n_box):
+            objs.append(host.Box(tuple(float(x) for x in rng.uniform(-20, 20, 3) + (0, 0, -30)), (float(rng.uniform(0.5, 2.0)),) * 3,
+                                 host.Lambertian(tuple(float(x) for x in rng.uniform(0.2, 1, 3)))))
+        return host.pack(objs, _abi.SHAPE_DTYPE)
+
+    w, h = 40, 24
+    cfg = rta.scenes.SceneConfig("crowd", many(1200, 250), np.zeros(0, dtype=_abi.TRIANGLE_DTYPE),
+                                 host.Camera(w, h, 1.0, (1, 1, 6)).data.copy(), w, h, 2, 5, sem, seed=9)
+    check_config(rta, orc, cfg)
+    cfg.shapes = many(2400, 500)
+    with pytest.raises(rta.RtError, match="LDS a workgroup can have"):
+        rta.scenes.make_renderer(cfg)
+
+
 @pytest.mark.parametrize("seed", [241, 847, 949, 3, 22, 47])
 def test_campaign_scenes(rta, orc, seed):
     """Scenes of the randomised campaign (tools/parity_campaign.py: all modes, flags, materials and shape kinds mixed).

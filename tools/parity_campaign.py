@@ -68,6 +68,11 @@ def random_config(seed):
         objs.append(host.Circle((1, 7 * spread, -4), 2.5 * spread, host.Light((3, 3, 3))))
     n_sph = int(rng.choice([0, 1, 3, 4, 5, 8, 13, 40]))
     n_box = int(rng.choice([0, 0, 1, 3, 7, 20]))
+    if seed >= CROWDED_FROM:                                  # scenes near what the LDS stage holds (64 KiB)
+        n_sph = int(rng.choice([0, 150, 400, 600, 1200, 1500]))
+        n_box = int(rng.choice([0, 60, 150, 300, 900]))
+        room = 160 * 1024 - 36 * 1024 - 90 * n_sph                # a workgroup's LDS less the waves' queues and a staged mesh
+        n_box = max(0, min(n_box, room // 120))
     n_cube = int(rng.choice([0, 0, 1, 2])) if sem == 0 else 0
     for _ in range(n_sph):
         objs.append(host.Circle(point(), float(rng.uniform(0.2, 1.0) * spread), material()))
@@ -97,6 +102,8 @@ def random_config(seed):
     tcol = rng.uniform(0.1, 1.0, (n_tris, 3)).astype(np.float32) if n_tris and rng.random() < 0.3 else None
 
     w, h = int(rng.integers(1, 120)), int(rng.integers(1, 70))
+    if seed >= CROWDED_FROM:
+        w, h, spp = int(rng.integers(1, 40)), int(rng.integers(1, 24)), (spp if grid_n else int(rng.integers(1, 3)))
     cam_pos = (1.0, 1.0, 6.0) if rng.random() < 0.6 else tuple(float(x) for x in np.array(point()) * rng.choice([1.0, 0.2]))
     cam = host.Camera(w, h, float(rng.choice([1.0, 0.5, 2.0])), cam_pos)
     if rng.random() < 0.3:
@@ -111,6 +118,7 @@ def random_config(seed):
 
 
 EXTENDED_FROM = 100000      # seeds from here on also get what extend() adds (earlier seeds keep their scenes)
+CROWDED_FROM = 400000       # and from here on hundreds of spheres and boxes on small frames
 
 
 def extend(cfg, r):
