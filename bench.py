@@ -231,7 +231,7 @@ def main():
 
     def say(*a):
         if verbose:
-            print(f"[rank {rank}]", *a, file=sys.stderr, flush=True)
+            print(f"[rank {rank} {time.strftime('%H:%M:%S')}]", *a, file=sys.stderr, flush=True)
 
     say("process group up")
     overrides = {"width": args.width, "height": args.height} if args.width and args.height else {}
@@ -288,8 +288,10 @@ def main():
             pending = None
             for k in range(n):
                 nxt = trace(0 if one_context else k, events[k] if events else None)
+                say(mode, "frame", k, "queued")
                 if pending is not None:
                     finish(pending)               # frame k-1: after frame k's trace is queued
+                    say(mode, "frame", k - 1, "finished")
                 if world == 1:
                     finish(nxt); nxt = None
                 pending = nxt
@@ -319,6 +321,7 @@ def main():
         say(mode, "warmup done")
         if world > 1:
             dist.barrier()
+        say(mode, "barrier passed")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run(args.steps)

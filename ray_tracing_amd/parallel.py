@@ -91,8 +91,13 @@ def reduce_framebuffer(accum_words, semantics, dst=0, group=None, async_op=False
         return None
     t = accum_view(accum_words, semantics)
     if t.is_cuda and dist.get_backend(group) == "gloo":
-        # gloo has no reduce for device tensors; its all_reduce gives rank `dst` the same sum (rehearsals only)
-        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        # Rehearsals only (ranks sharing one GPU, gloo between them): summed through host memory and completed
+        # here — gloo's own handling of device tensors was seen to stall on the second 33 MB frame.
+        host = t.cpu()
+        dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if dist.get_rank(group) == dst:
+            t.copy_(host)
+        return None
     return dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
