@@ -600,6 +600,37 @@ def test_random_scenes(rta, orc, seed):
     check_config(rta, orc, cfg, trace_samples=(0, 2))
 
 
+def test_two_contexts_on_two_streams(rta, orc):
+    """Two contexts, each on a stream of its own, with frames queued alternately and nothing waited for in between (how
+    bench.py keeps two frames in flight): the launches overlap on the GPU and neither frame may change."""
+    import torch
+    cfgs = [rta.scenes.config3(width=320, height=200, spp=70, max_depth=8), rta.scenes.config2(width=400, height=240, spp=40, max_depth=8)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    rts, bufs, refs = [], [], []
+    for cfg, st in zip(cfgs, streams):
+        rt = rta.scenes.make_renderer(cfg)
+        rt.setStream(st.cuda_stream)
+        buf = torch.zeros(cfg.height, cfg.width, 4, dtype=torch.int32, device="cuda")
+        rt.bindAccum(buf.data_ptr(), cfg.width, cfg.height)
+        rts.append(rt); bufs.append(buf)
+        acc, _ = orc.render(cfg.shapes, cfg.triangles, cfg.camera, oracle_params(orc, cfg))
+        refs.append(np.ascontiguousarray(acc).view(np.uint32)[..., :3])
+    torch.cuda.synchronize()
+    try:
+        for frame in range(4):                         # frame 0 probes and plans, the later ones run by the plan
+            for cfg, rt in zip(cfgs, rts):
+                rt.resetAccum()
+                rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed)
+        torch.cuda.synchronize()
+        for cfg, buf, ref in zip(cfgs, bufs, refs):
+            got = buf.cpu().numpy().view(np.uint32)[..., :3]
+            assert np.array_equal(got, ref), f"{cfg.name}: {int((got != ref).sum())} accumulator words differ"
+    finally:
+        for rt in rts:
+            rt.bindAccum(None, 0, 0)
+            rt.close()
+
+
 @pytest.mark.parametrize("sem", [0, 1])
 def test_many_hundred_shapes(rta, orc, sem):
     """The shapes are staged in LDS whatever their number: 1 200 spheres and 250 boxes take 140 KiB of a workgroup's
