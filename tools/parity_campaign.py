@@ -5,7 +5,7 @@ sample modes, both draw streams, the flags, cubes, dielectrics, debug and unknow
 sides, triangle colours, meshes from none to a few thousand triangles (staged in LDS or read from global memory),
 cameras inside and outside the scene, ragged frame sizes, depths 1 .. 9.
 
-    python tools/parity_campaign.py [--calls] [n_scenes] [first_seed]       # needs an MI355X; prints one line per failure
+    python tools/parity_campaign.py [--calls [--big]] [n_scenes] [first_seed]       # needs an MI355X; prints one line per failure
 
 With --calls every scene (64 .. 100 samples per pixel) goes through every way of calling the renderer instead (see
 run_calls) and the accumulators are compared.
@@ -204,6 +204,12 @@ def run_calls(seed):
     cfg.spp = int(rng.integers(64, 101))
     cfg.max_depth = min(cfg.max_depth, 6)
     cfg.width, cfg.height = int(rng.integers(1, 73)), int(rng.integers(1, 49))
+    if BIG_FRAMES:                                            # hundreds of tiles: plans with many entries and slices
+        cfg.width, cfg.height, cfg.spp = int(rng.integers(100, 401)), int(rng.integers(60, 301)), int(rng.integers(64, 81))
+        cfg.max_depth = min(cfg.max_depth, 4)
+        if len(cfg.triangles) > 150:
+            cfg.triangles = cfg.triangles[:150]
+            cfg.triangle_colors = None if cfg.triangle_colors is None else cfg.triangle_colors[:150]
     cam = host.Camera(cfg.width, cfg.height, 1.0, tuple(float(x) for x in cfg.camera[0:3]))
     cfg.camera = cam.data.copy()
     if len(cfg.triangles) > 300:
@@ -270,10 +276,17 @@ def run_calls(seed):
     return cfg, ostats, problems
 
 
+BIG_FRAMES = False
+
+
 def main():
+    global BIG_FRAMES
     calls = "--calls" in sys.argv
     if calls:
         sys.argv.remove("--calls")
+    if "--big" in sys.argv:                                   # with --calls: frames of 100x60 .. 400x300 pixels
+        sys.argv.remove("--big")
+        BIG_FRAMES = True
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     t0 = time.time()
