@@ -190,3 +190,41 @@ def test_hemisphere_sampler(literal):
         u1, u2 = f(rng.integers(0, 1 << 24)) / f(1 << 24), f(rng.integers(0, 1 << 24)) / f(1 << 24)
         worst = max(worst, float(np.abs(hemisphere(n, u1, u2) - orc.hemisphere_glsl(n, float(u1), float(u2))).max()))
     assert worst <= 2e-7
+
+
+def cube_hit(R, c, o, d):                        # Cube::hit, src/cpu_version/scene.h:185-204
+    oc = o - c
+    ot = np.array([dot(R[i], oc) for i in range(3)], dtype=f)
+    dt = np.array([dot(R[i], d) for i in range(3)], dtype=f)
+    sg = np.array([sign(x) for x in ot], dtype=f)
+    with np.errstate(all="ignore"):
+        t = (f(0.5) - ot * sg) / (sg * dt)
+        for k in range(3):
+            p = ot + dt * t[k]
+            if max(abs(p[0]), abs(p[1]), abs(p[2])) == f(0.5):       # :193: exactly on the surface, first axis that is
+                return t[k], p
+    return None
+
+
+def test_cube_of_the_cpu_tracer_bit_for_bit(literal, rta):
+    """The Cube accepts a point only when its infinity norm is exactly 0.5, so every rounding is part of the result:
+    which rays hit, at what distance, and the point in the cube's frame that its normal is taken from."""
+    from ray_tracing_amd import host
+    orc = literal
+    rng = np.random.default_rng(1)
+    hits = 0
+    for i in range(3000):
+        cube = host.Cube(tuple(rng.uniform(-2, 2, 3)), host.Lambertian((0.5, 0.5, 0.5)))
+        if i % 3:
+            cube.rotate(float(rng.uniform(-1, 1)))                    # scene.h:206-208
+        m = cube.rec["transformation"].reshape(4, 4).T
+        rot, c = m[:3, :3].astype(f), m[:3, 3].astype(f)
+        o = rng.uniform(-4, 4, 3).astype(f)
+        d = c + rng.uniform(-0.4, 0.4, 3).astype(f) - o
+        d = (d / np.linalg.norm(d)).astype(f)
+        a, b = cube_hit(rot, c, o, d), orc.hit_cube(cube.rec["transformation"], o, d)
+        assert (a is None) == (b is None)
+        if a is not None:
+            hits += 1
+            assert same_bits(a[0], b[0]) and same_bits(a[1], b[1])
+    assert hits > 1000
