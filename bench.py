@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--mesh", default="", help="c3 only: the mesh file under ray_tracing_amd/data (default Bunny-LowPoly.off; bunny.off has 4 968 triangles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="one GPU: frames in flight, each on its own context and stream (1: one after the other)")
+    ap.add_argument("--settle-ms", type=float, default=250.0, help="untimed frames before the warm-up steps, for this long, so that the device has reached its sustained clock (0: none)")
     ap.add_argument("--no-live-counters", action="store_true", help="do not run the rocprofv3 --pmc passes; roofline.traffic then comes from profiles/traffic.json")
     ap.add_argument("--counters-child", action="store_true", help=argparse.SUPPRESS)   # this run is one of those passes
     args = ap.parse_args()
@@ -317,6 +318,23 @@ def main():
             cold_ms = (time.perf_counter() - tc) * 1e3
             rt_cold.bindAccum(None, 0, 0)
             rt_cold.close()
+        # Device clocks.  After the idle stretch above (contexts created and freed) the GPU runs below its sustained
+        # clock and takes some 20 ms of load to reach it (tools/frame_gaps.py: frames of C2 last 1.20 ms, then 1.15,
+        # ... 1.03 from the twentieth on); K timed steps of a millisecond each would measure that ramp, not the
+        # renderer.  So the same frames run untimed for SETTLE_S first — every rank the same number, the count
+        # derived from the slowest rank's time for the first few — and the line says how many ("clock_settle_frames").
+        settle_frames = 0
+        if not args.counters_child and args.settle_ms > 0:
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            run(4)
+            torch.cuda.synchronize()
+            per = torch.tensor([(time.perf_counter() - ts) / 4.0], dtype=torch.float64, device="cuda")
+            if world > 1:
+                dist.all_reduce(per, op=dist.ReduceOp.MAX)
+            settle_frames = int(min(2000, max(0, round(args.settle_ms * 1e-3 / max(float(per.item()), 1e-6)) - 4)))
+            run(settle_frames)
+            settle_frames += 4
         run(args.warmup)
         say(mode, "warmup done")
         if world > 1:
@@ -345,7 +363,7 @@ def main():
         if world > 1:
             dist.all_reduce(samples)
         m = {"shard": shard, "stats": stats, "elapsed": float(t.item()), "samples_per_step": int(samples.item()),
-             "kernel_ms": kernel_ms, "cold_ms": cold_ms, "rts": rts, "accums": accums}
+             "kernel_ms": kernel_ms, "cold_ms": cold_ms, "rts": rts, "accums": accums, "settle_frames": settle_frames}
         return m
 
     def release(m):
@@ -438,6 +456,8 @@ def main():
             # no samples left while their wave went on)
             "lane_use": round(stats["segments"] / max(1, 64 * stats["wave_iterations"]), 4),
             "cold_first_frame_ms": None if cold_ms is None else round(cold_ms, 4),
+            # untimed frames run before the warm-up steps so that the device is at its sustained clock (--settle-ms)
+            "clock_settle_frames": m["settle_frames"],
             "roofline": {"bound": bound, "achieved": round(achieved, 3), "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "trace_kernel", "kernel_ms": round(kernel_ms, 4),

@@ -290,7 +290,8 @@ class RayTracingComputeShader:
             self._ctx = C.c_void_p()
 
     def __del__(self):
-        self.close()
+        if lib is not None:               # at interpreter shutdown the module's globals may already be gone
+            self.close()
 
     def _check(self, rc):
         if rc != 0:
