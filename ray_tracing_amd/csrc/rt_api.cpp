@@ -86,6 +86,7 @@ struct rt_ctx {
     // Switches for measurements, read from the environment once, when the context is created.
     uint32_t group_waves = 4;           // waves per workgroup (RT_GROUP_WAVES: 1 .. 8, for measurements)
     bool env_no_tile_order = false, env_no_slices = false, env_mesh_in_lds = false, env_no_probe = false;
+    uint32_t env_leaf = 0;               // RT_LEAF: triangles per tree leaf for every mesh (measurements); 0: chosen by mesh size
     float slice_share = 0.25f, slice_early = 0.5f;       // RT_SLICE_SHARE, RT_SLICE_EARLY (measurements)
     uint32_t slice_min_spp = 16u, slice_max = 16u;       // RT_SLICE_MIN_SPP, RT_SLICE_MAX
     uint32_t probe_spp = 0u;                             // RT_PROBE_SPP (0: the built-in PROBE_SPP)
@@ -152,6 +153,7 @@ static void build_tree(const std::vector<rt_triangle>& tris, const rtd::SceneLay
                        uint32_t n_tri_pad, std::vector<Word>& blob)
 {
     const uint32_t n = (uint32_t)tris.size();
+    const uint32_t leaf = 1u << L.leaf_shift;               // triangles per leaf of this mesh's tree
     std::vector<TriGeom> g(n);
     for (uint32_t i = 0; i < n; ++i) {
         const rt_triangle& t = tris[i];
@@ -171,7 +173,7 @@ static void build_tree(const std::vector<rt_triangle>& tris, const rtd::SceneLay
     }
     // Order the triangles by recursive median splits along the longest axis of their centroids'
     // extent (degenerate ones last).  Split points fall on multiples of the largest tree block
-    // (TREE_LEAF * TREE_FAN^k) that is smaller than the range, so every node of the implicit
+    // (leaf * TREE_FAN^k) that is smaller than the range, so every node of the implicit
     // tree bounds one spatially compact run.  Measured against a Morton sort: the summed squared
     // leaf radius (the chance of a ray entering a leaf) falls by a quarter on the 292-triangle
     // bunny and by more than half on the 4 968-triangle one.
@@ -186,8 +188,8 @@ static void build_tree(const std::vector<rt_triangle>& tris, const rtd::SceneLay
     while (!todo.empty()) {
         const Range r = todo.back(); todo.pop_back();
         const uint32_t len = r.hi - r.lo;
-        if (len <= rtd::TREE_LEAF) continue;
-        uint32_t block = rtd::TREE_LEAF;
+        if (len <= leaf) continue;
+        uint32_t block = leaf;
         while ((uint64_t)block * rtd::TREE_FAN < len) block *= rtd::TREE_FAN;
         // the multiple of `block` nearest to the middle, strictly inside the range
         uint32_t h = ((len / 2u + block / 2u) / block) * block;
@@ -244,7 +246,7 @@ static void build_tree(const std::vector<rt_triangle>& tris, const rtd::SceneLay
         }
     }
     // Level l node i covers the sorted triangles [span*i, span*(i+1)), span = LEAF * FAN^l.
-    uint32_t span = rtd::TREE_LEAF;
+    uint32_t span = leaf;
     for (uint32_t l = 0; l < rtd::TREE_LEVELS; ++l, span *= rtd::TREE_FAN) {
         for (uint32_t i = 0; i < node_pad[l]; ++i) {
             Word& w = blob[L.node_off[l] + i];
@@ -328,9 +330,14 @@ static int plan_blob(rt_ctx* ctx, BlobPlan& B)
     L.sid_off = L.sph_off + L.n_sph_pad;
     L.box_off = L.sid_off + L.n_sph_pad / 4u;
     // Bounding-sphere tree over the triangles (rt_device.h).
-    const uint32_t n_tri_pad = (n_tris + rtd::TREE_LEAF - 1u) / rtd::TREE_LEAF * rtd::TREE_LEAF;
+    // Leaves of a small mesh hold half as many triangles (rt_device.h).
+    uint32_t leaf = n_tris <= rtd::SMALL_MESH_TRIS ? rtd::TREE_LEAF_SMALL : rtd::TREE_LEAF;
+    if (ctx->env_leaf && n_tris / ctx->env_leaf < (1u << 24)) leaf = ctx->env_leaf;      // a leaf's number must fit 24 bits
+    for (L.leaf_shift = 0; (1u << (L.leaf_shift + 1u)) <= leaf; ++L.leaf_shift) {}
+    leaf = 1u << L.leaf_shift;
+    const uint32_t n_tri_pad = (n_tris + leaf - 1u) / leaf * leaf;
     {
-        uint32_t n = n_tri_pad / rtd::TREE_LEAF;
+        uint32_t n = n_tri_pad / leaf;
         for (uint32_t l = 0; l < rtd::TREE_LEVELS; ++l) {
             L.node_n[l] = n;
             B.node_pad[l] = (n + rtd::TREE_FAN - 1u) / rtd::TREE_FAN * rtd::TREE_FAN;
@@ -529,6 +536,7 @@ int rt_create(rt_ctx** out, const rt_config* cfg)
     ctx->env_no_tile_order = env_on("RT_NO_TILE_ORDER");
     ctx->env_no_slices = env_on("RT_NO_SLICES");
     ctx->env_mesh_in_lds = env_on("RT_MESH_IN_LDS");
+    if (const char* v = getenv("RT_LEAF")) { const int n = atoi(v); if (n >= 1 && n <= (int)rtd::TREE_LEAF && (n & (n - 1)) == 0) ctx->env_leaf = (uint32_t)n; }
     ctx->env_no_probe = env_on("RT_NO_PROBE");
     if (const char* v = getenv("RT_SLICE_SHARE")) { const float f = (float)atof(v); if (f > 0.0f) ctx->slice_share = f; }
     if (const char* v = getenv("RT_SLICE_EARLY")) { const float f = (float)atof(v); if (f > 0.0f) ctx->slice_early = f; }

@@ -33,13 +33,15 @@ namespace rtd {
 //                         centre, {R(i,0), R(i,1), R(i,2), c_i} for i = 0..2, then {shape index, 0, 0, 0}
 //   node [n3p+n2p+n1p+n0p] bounding spheres over the triangles, four levels (below)
 //   tri  [4 * n_tri_pad]  SimpleTriangles ordered by recursive median splits and padded to a
-//                         multiple of TREE_LEAF with never-hit ones: {position.xyz, index in
+//                         multiple of the leaf size with never-hit ones: {position.xyz, index in
 //                         the uploaded array}, {a.xyz, beta}, {m1}, {m2}
 //   inv  [n_tris / 4]     never staged in LDS: for each uploaded triangle, its place in the sorted list (uint32)
 //   tcol [n_tris]         optional, never staged in LDS: albedo.rgb of each uploaded triangle (x 0.6 under CPU rules)
 //
-// Bounding-sphere tree: level 0 node i bounds the sorted triangles [TREE_LEAF*i,
-// TREE_LEAF*(i+1)); a node i of level l+1 bounds the nodes [TREE_FAN*i, TREE_FAN*(i+1)) of
+// Bounding-sphere tree: level 0 node i (a leaf) bounds the sorted triangles [leaf*i, leaf*(i+1)), leaf =
+// 1 << SceneLayout::leaf_shift — chosen per mesh at upload: TREE_LEAF, or half of it for a mesh of at most
+// SMALL_MESH_TRIS triangles (measured: leaves of two are 3 % faster than leaves of four on a 292-triangle mesh
+// and 3-4 % slower on a 4 968-triangle one); a node i of level l+1 bounds the nodes [TREE_FAN*i, TREE_FAN*(i+1)) of
 // level l.  Every level is padded to a multiple of TREE_FAN with never-hit nodes (NaN
 // centre).  A node is {centre.xyz, R}, R = 1.01 * radius + 1e-4 (radius: of a small enclosing ball of the node's vertices): the slack covers the
 // rounding of the triangle test itself, so that a ray the triangle test could accept is
@@ -51,6 +53,9 @@ namespace rtd {
 #define RT_TREE_FAN 8
 #endif
 constexpr uint32_t TREE_LEAF = RT_TREE_LEAF, TREE_FAN = RT_TREE_FAN, TREE_LEVELS = 4;
+constexpr uint32_t SMALL_MESH_TRIS = 1024u;
+constexpr uint32_t TREE_LEAF_SMALL = TREE_LEAF >= 2u ? TREE_LEAF / 2u : TREE_LEAF;
+static_assert((TREE_LEAF & (TREE_LEAF - 1u)) == 0u, "a leaf holds a power of two of triangles (lanes of a pass find theirs by shift and mask)");
 struct SceneLayout {
     uint32_t n_shapes, n_sph_pad, n_box, n_cube, n_tris;
     uint32_t rec_off, sph_off, sid_off, box_off, cub_off, inv_off, tri_off;   // in 16-byte words
@@ -62,6 +67,7 @@ struct SceneLayout {
     uint32_t has_glass;                                     // 1 if any shape has the dielectric material
     uint32_t tcol_off;                                      // 0: all triangles share TraceParams::tri_albedo
     uint32_t has_debug;                                     // 1 if any shape has the debug material
+    uint32_t leaf_shift;                                    // a leaf of this scene's tree holds 1 << leaf_shift triangles (<= TREE_LEAF)
 };
 
 // Everything one trace launch needs besides the blob; passed by value in the
@@ -122,7 +128,7 @@ constexpr uint32_t NODE_STACK_STAGED = RT_NODE_STACK_STAGED, NODE_STACK_GLOBAL =
 // What is left below a full pass, plus what one step can add, must fit (64 lanes; a pass takes 64 / TREE_LEAF pairs
 // or 64 / TREE_FAN triples and can put 64 new ones there; three levels above the leaves).
 static_assert(TREE_LEAF >= 1u && TREE_LEAF <= 64u && TREE_FAN >= 2u && TREE_FAN <= 64u && SPREAD_BELOW <= 64u, "tree shape");
-static_assert((64u / TREE_LEAF - 1u) + 64u <= QUEUE_ENTRIES, "the leaf queue overflows");
+static_assert((64u / TREE_LEAF_SMALL - 1u) + 64u <= QUEUE_ENTRIES, "the leaf queue overflows");
 static_assert((64u / TREE_FAN - 1u) + (SPREAD_BELOW - 1u) <= NODE_STACK_STAGED, "the node stack of a staged mesh overflows");
 static_assert((64u / TREE_FAN - 1u) + (SPREAD_BELOW - 1u) + (TREE_LEVELS - 2u) * (64u - 64u / TREE_FAN) + 64u <= NODE_STACK_GLOBAL,
               "the node stack of a mesh in global memory overflows");

@@ -855,11 +855,12 @@ void trace_kernel(const TraceParams P,
         // ray's lane by an atomic minimum on (key, id) — the same order-independent minimum as everywhere else —
         // and every lane folds its slot into its closest hit when the walk is over.
         if (HAS_QUEUES) {
-            const uint32_t per_pass = n_live / TREE_LEAF;         // pairs one pass takes: TREE_LEAF lanes each
+            const uint32_t leaf_shift = L.leaf_shift, leaf_size = 1u << leaf_shift;     // triangles per leaf: chosen per mesh
+            const uint32_t per_pass = n_live >> leaf_shift;       // pairs one pass takes: one lane per triangle of the leaf
             uint32_t q_head = 0u, q_len = 0u;                     // wave-uniform
             auto pass = [&](uint32_t count) {
                 RT_PHASE_MARK3(1)
-                const uint32_t e = lane_rank / TREE_LEAF, k = lane_rank % TREE_LEAF;
+                const uint32_t e = lane_rank >> leaf_shift, k = lane_rank & (leaf_size - 1u);
                 const bool work = e < count;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const uint32_t ent = work ? queue[(q_head + e) & (QUEUE_ENTRIES - 1u)] : (lane << 24);
@@ -873,7 +874,7 @@ void trace_kernel(const TraceParams P,
                                  __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(d.y))),
                                  __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(d.z))));
                 if (work) {
-                    const float4* const t4 = tri + 4u * (TREE_LEAF * leaf + k);
+                    const float4* const t4 = tri + 4u * ((leaf << leaf_shift) + k);
                     float4 w0 = t4[0], w1 = t4[1], w2 = t4[2], w3 = t4[3];
                     if (!TRI_GLOBAL) asm volatile("" : "+v"(w0.w), "+v"(w2.w), "+v"(w3.w));    // whole 16-byte LDS reads (see the direct path)
                     uint32_t ckey, cid;
@@ -970,9 +971,8 @@ void trace_kernel(const TraceParams P,
                             const unsigned long long touching = __ballot(touch);
                             if (touching == 0ull) continue;
                             if (spread) { push_leaves(touch, lane, i0); continue; }
-#pragma unroll
-                            for (uint32_t k = 0; k < TREE_LEAF; ++k) {
-                                const uint32_t ti = TREE_LEAF * i0 + k;
+                            for (uint32_t k = 0; k < leaf_size; ++k) {
+                                const uint32_t ti = (i0 << leaf_shift) + k;
                                 float4 w0 = tri[4u * ti], w1 = tri[4u * ti + 1u], w2 = tri[4u * ti + 2u], w3 = tri[4u * ti + 3u];
                                 // Only xyz of two of the words is used, which would let the compiler
                                 // fetch 12 bytes each — and a 12-byte LDS read costs twice the LDS
@@ -980,7 +980,7 @@ void trace_kernel(const TraceParams P,
                                 if (!TRI_GLOBAL) asm volatile("" : "+v"(w2.w), "+v"(w3.w));
                                 test_triangle<SEM>(w0, w1, w2, w3, n_shapes, o, d, best);
                             }
-                            if (STATS) n_tri += TREE_LEAF;
+                            if (STATS) n_tri += leaf_size;
                         }
                     }
                 }
