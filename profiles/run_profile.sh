@@ -8,8 +8,9 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 EXTRA=${BENCH_EXTRA:-}
-# --streams 1: one frame in flight, so that a launch's duration and counters are its own
-BENCH="python3 $ROOT/bench.py --steps ${PMC_STEPS:-5} --warmup 1 --no-cpu-baseline --streams 1 $EXTRA"
+# --streams 1: one frame in flight, so that a launch's duration and counters are its own; the counter passes skip the
+# frames that bring the device to its sustained clock (counters do not depend on it), the timed trace run keeps them
+BENCH="python3 $ROOT/bench.py --steps ${PMC_STEPS:-5} --warmup 1 --no-cpu-baseline --settle-ms 0 --streams 1 $EXTRA"
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ROOT/bench.py --steps ${TRACE_STEPS:-10} --warmup 2 --no-cpu-baseline --streams 1 $EXTRA > "$OUT/trace.log" 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc1" -- $BENCH > "$OUT/pmc1.log" 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS --output-format csv -d "$OUT/pmc2" -- $BENCH > "$OUT/pmc2.log" 2>&1

@@ -324,7 +324,7 @@ static int plan_blob(rt_ctx* ctx, BlobPlan& B)
         else if (s.type == RT_SHAPE_CUBE && ctx->cfg.semantics == RT_SEM_CPU) ++n_cube;
     }
     rtd::SceneLayout L{};
-    L.n_shapes = n_shapes; L.n_sph_pad = (n_sph + 3u) & ~3u; L.n_box = n_box; L.n_cube = n_cube; L.n_tris = n_tris;
+    L.n_shapes = n_shapes; L.n_sph_pad = (n_sph + 3u) & ~3u; L.n_sph = n_sph; L.n_box = n_box; L.n_cube = n_cube; L.n_tris = n_tris;
     L.rec_off = 0;
     L.sph_off = L.rec_off + 4u * (n_shapes + 1u);          // one record more: what a miss reads
     L.sid_off = L.sph_off + L.n_sph_pad;

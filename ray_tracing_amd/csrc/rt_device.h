@@ -67,6 +67,7 @@ struct SceneLayout {
     uint32_t has_glass;                                     // 1 if any shape has the dielectric material
     uint32_t tcol_off;                                      // 0: all triangles share TraceParams::tri_albedo
     uint32_t has_debug;                                     // 1 if any shape has the debug material
+    uint32_t n_sph;                                         // spheres uploaded (n_sph_pad less the padding)
     uint32_t leaf_shift;                                    // a leaf of this scene's tree holds 1 << leaf_shift triangles (<= TREE_LEAF)
 };
 

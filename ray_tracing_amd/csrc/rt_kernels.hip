@@ -46,6 +46,12 @@ namespace rtd {
 #ifndef RT_QUEUE_WAVES
 #define RT_QUEUE_WAVES 7
 #endif
+// A box that at least NUM / DEN of the live lanes touch is tested by the whole wave on the spot instead of through the queue.
+// (Measured on the mesh scene, four boxes of which one is the floor: never on the spot 14.51 ms, from 3/4 of the lanes 14.39, from 1/2 14.34.)
+#ifndef RT_BOX_DIRECT_NUM
+#define RT_BOX_DIRECT_NUM 1u
+#define RT_BOX_DIRECT_DEN 2u
+#endif
 // Measurement build (-DRT_PHASE_CLOCKS=1): the timeline record of a wave holds, instead of its start and end, the
 // shader clocks / 16 its loop spent in the sphere scan, the boxes and cubes, the triangle tree, and the rest
 // (surface, draws, new direction); tools/phase_clocks.py sums them.
@@ -707,7 +713,7 @@ void trace_kernel(const TraceParams P,
     const float4* const node1 = nodes + L.node_off[1];
     const float4* const node2 = nodes + L.node_off[2];
     const float4* const node3 = nodes + L.node_off[3];
-    const uint32_t n_chunks = L.n_sph_pad >> 2, n_box = L.n_box, n_shapes = L.n_shapes;
+    const uint32_t n_chunks = L.n_sph >> 2, n_sph = L.n_sph, n_box = L.n_box, n_shapes = L.n_shapes;     // whole chunks of four spheres
     // Behind the staged scene every wave has a queue of (lane, leaf) or (lane, box) pairs waiting for their tests,
     // one slot per lane for the closest hit those tests found, and a stack of tree nodes (rt_device.h).
     uint32_t* const queue = reinterpret_cast<uint32_t*>(lds + L.lds_words + (tid >> 6) * (TRI_GLOBAL ? WAVE_LDS_WORDS_GLOBAL : WAVE_LDS_WORDS));
@@ -763,6 +769,9 @@ void trace_kernel(const TraceParams P,
             test_sphere<SEM>(s2, __float_as_uint(ids.z), o, d, best);
             test_sphere<SEM>(s3, __float_as_uint(ids.w), o, d, best);
         }
+        // the one to three spheres behind the last whole chunk, one at a time: the padding of their chunk is not tested
+        for (uint32_t i = 4u * n_chunks; i < n_sph; ++i)
+            test_sphere<SEM>(sph[i], reinterpret_cast<const uint32_t*>(sid)[i], o, d, best);
         if (HAS_QUEUES || HAS_CUBE) best.key = (best.id == NONE) ? Window<SEM>::far - 1u - Window<SEM>::tmin : best.key;
         RT_PHASE_MARK(0)
         // The lanes still tracing, and this lane's place among them: they share the queued tests.
@@ -809,7 +818,7 @@ void trace_kernel(const TraceParams P,
                 const unsigned long long touching = __ballot(touch);
                 if (touching == 0ull) continue;
                 const uint32_t n_touching = (uint32_t)__popcll(touching);
-                if (2u * n_touching >= n_live) {
+                if (RT_BOX_DIRECT_DEN * n_touching >= RT_BOX_DIRECT_NUM * n_live) {
                     // Nearly every lane wants this box (a floor): the wave tests it on the spot, without the queue.
                     const float4 bx1 = box[3u * i + 1u];
                     take_if_closer(best, __float_as_uint(hit_box(bc, bx1.y, bx1.z, o, d)) - Window<SEM>::tmin, __float_as_uint(bx1.x));
