@@ -476,7 +476,19 @@ def main():
                 rt.render(cfg.width, cfg.height, spp, cfg.max_depth, cfg.seed)
                 torch.cuda.synchronize()
                 return accums[0].cpu().numpy().view("uint32")
-            result["cpu_baseline"] = cpu_baseline(cfg, gpu_render=gpu_render)
+            # The CPU legs are single library calls of up to a minute each and print nothing; a harness that takes a
+            # silent run for a hung one gets a line on stderr every half minute.
+            import threading
+            done = threading.Event()
+
+            def heartbeat():
+                while not done.wait(30.0):
+                    print("[bench] CPU baseline running", file=sys.stderr, flush=True)
+            threading.Thread(target=heartbeat, daemon=True).start()
+            try:
+                result["cpu_baseline"] = cpu_baseline(cfg, gpu_render=gpu_render)
+            finally:
+                done.set()
         print(json.dumps(result), flush=True)
 
     release(m)
