@@ -567,6 +567,38 @@ def test_small_mesh_staged_in_lds(rta, orc, monkeypatch):
     check_config(rta, orc, rta.scenes.config3(width=96, height=54, spp=4, max_depth=8))
 
 
+@pytest.mark.parametrize("mesh, staged", [("Bunny-LowPoly.off", False), ("Bunny-LowPoly.off", True), ("bunny.off", False)])
+def test_every_leaf_size_gives_the_same_frame(rta, orc, monkeypatch, mesh, staged):
+    """The tree's leaves hold two triangles for a small mesh and four for a large one (chosen at upload); RT_LEAF sets
+    the size for measurements.  The closest hit is a minimum over the same tests whatever the tree's shape: leaves of
+    one, two and four triangles give the same words, counters included, on both meshes, staged in LDS or not, and
+    the small mesh's equal the oracle's."""
+    cfg = rta.scenes.config3(width=160, height=96, spp=8, max_depth=8, mesh=mesh)
+    if staged:
+        monkeypatch.setenv("RT_MESH_IN_LDS", "1")
+    frames = {}
+    for leaf in ("1", "2", "4", None):
+        if leaf is None:
+            monkeypatch.delenv("RT_LEAF")
+        else:
+            monkeypatch.setenv("RT_LEAF", leaf)
+        rt = rta.scenes.make_renderer(cfg)
+        try:
+            stats = rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, stats=True)
+            frames[leaf] = (rt.resolve(cfg.width, cfg.height).view(np.uint32).copy(), {k: stats[k] for k in COUNTERS},
+                            stats["triangle_tests_done"])
+        finally:
+            rt.close()
+    for leaf in ("1", "2", "4"):
+        np.testing.assert_array_equal(frames[leaf][0], frames[None][0])
+        assert frames[leaf][1] == frames[None][1]
+    assert frames[None][2] == frames["2" if mesh == "Bunny-LowPoly.off" else "4"][2]      # the default is the size chosen by mesh size
+    assert frames["1"][2] < frames["2"][2] < frames["4"][2]                               # smaller leaves, fewer triangle tests
+    if mesh == "Bunny-LowPoly.off":
+        acc, ostats = orc.render(cfg.shapes, cfg.triangles, cfg.camera, oracle_params(orc, cfg))
+        np.testing.assert_array_equal(frames[None][0], orc.resolve(acc, cfg.spp, cfg.semantics).view(np.uint32))
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_scenes(rta, orc, seed):
     """Random mixtures of spheres, boxes and loose triangles with random materials, under both rule sets: the queued
