@@ -41,7 +41,7 @@ namespace rtd {
 // Bounding-sphere tree: level 0 node i (a leaf) bounds the sorted triangles [leaf*i, leaf*(i+1)), leaf =
 // 1 << SceneLayout::leaf_shift — chosen per mesh at upload: TREE_LEAF, or half of it for a mesh of at most
 // SMALL_MESH_TRIS triangles (measured: leaves of two are 3 % faster than leaves of four on a 292-triangle mesh
-// and 3-4 % slower on a 4 968-triangle one); a node i of level l+1 bounds the nodes [TREE_FAN*i, TREE_FAN*(i+1)) of
+// and 3-4 % slower on a 4 968-triangle one; on its first 600 / 1 000 / 1 500 / 2 200 / 3 200 faces: 1 % faster, 0.7 / 1.7 / 3.4 / 5.9 % slower); a node i of level l+1 bounds the nodes [TREE_FAN*i, TREE_FAN*(i+1)) of
 // level l.  Every level is padded to a multiple of TREE_FAN with never-hit nodes (NaN
 // centre).  A node is {centre.xyz, R}, R = 1.01 * radius + 1e-4 (radius: of a small enclosing ball of the node's vertices): the slack covers the
 // rounding of the triangle test itself, so that a ray the triangle test could accept is
@@ -53,7 +53,7 @@ namespace rtd {
 #define RT_TREE_FAN 8
 #endif
 constexpr uint32_t TREE_LEAF = RT_TREE_LEAF, TREE_FAN = RT_TREE_FAN, TREE_LEVELS = 4;
-constexpr uint32_t SMALL_MESH_TRIS = 1024u;
+constexpr uint32_t SMALL_MESH_TRIS = 800u;
 constexpr uint32_t TREE_LEAF_SMALL = TREE_LEAF >= 2u ? TREE_LEAF / 2u : TREE_LEAF;
 static_assert((TREE_LEAF & (TREE_LEAF - 1u)) == 0u, "a leaf holds a power of two of triangles (lanes of a pass find theirs by shift and mask)");
 struct SceneLayout {

@@ -448,10 +448,10 @@ def test_far_edge_of_the_window_is_exclusive(rta, orc):
             rt.close()
 
 
-@pytest.mark.parametrize("n_tris", [1, 5, 101, 290, 1024, 1025, 1303])
+@pytest.mark.parametrize("n_tris", [1, 5, 101, 290, 800, 801, 1303])
 def test_triangle_count_not_a_multiple_of_the_leaf(rta, orc, n_tris):
     """Both meshes of the reference happen to hold a multiple of four triangles (292, 4 968); the tree's
-    leaves hold two triangles for a mesh of up to 1 024 and four beyond, so other counts exercise its
+    leaves hold two triangles for a mesh of up to 800 and four beyond, so other counts exercise its
     padding, on both sides of that border."""
     cfg = rta.scenes.config3(width=96, height=54, spp=4, max_depth=6, mesh="Bunny-LowPoly.off" if n_tris <= 292 else "bunny.off")
     cfg.triangles = cfg.triangles[:n_tris].copy()
