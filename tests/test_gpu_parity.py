@@ -253,9 +253,9 @@ def test_first_frame_of_a_fresh_context_equals_the_oracle(rta, orc):
         rt.close()
 
 
-@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5"])
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5", "c5e"])
 def test_full_size_properties(rta, name, monkeypatch):
-    """Configurations 2-5 at their full sizes: properties that need no oracle run (counters, idempotence, linearity in
+    """Configurations 2-5 (and 5 enclosed in its room of wall boxes) at their full sizes: properties that need no oracle run (counters, idempotence, linearity in
     the sample split, seed independence of the mean; for the mesh scene also: the frame does not depend on the launch
     plan — tile order, slices of the sample range — or on where the mesh lives)."""
     cfg = rta.scenes.CONFIGS[name]()
