@@ -321,7 +321,7 @@ def main():
         # Device clocks.  After the idle stretch above (contexts created and freed) the GPU runs below its sustained
         # clock and takes some 20 ms of load to reach it (tools/frame_gaps.py: frames of C2 last 1.20 ms, then 1.15,
         # ... 1.03 from the twentieth on); K timed steps of a millisecond each would measure that ramp, not the
-        # renderer.  So the same frames run untimed for SETTLE_S first — every rank the same number, the count
+        # renderer.  So the same frames run untimed for --settle-ms first (at most 2 000 of them) — every rank the same number, the count
         # derived from the slowest rank's time for the first few — and the line says how many ("clock_settle_frames").
         settle_frames = 0
         if not args.counters_child and args.settle_ms > 0:
