@@ -152,7 +152,7 @@ public:
     std::vector<float> triangleColors() const
     {
         std::vector<float> rgb(3 * triangles.size());
-        rt_mesh_triangle_colors(mesh, rgb.data());
+        if (rt_mesh_triangle_colors(mesh, rgb.data()) != RT_OK) throw std::out_of_range("SimpleMesh: a face names a vertex the mesh does not have");
         return rgb;
     }
 
@@ -181,6 +181,9 @@ public:
         std::vector<SimpleTriangle> out;
         out.reserve(triangles.size());
         for (const Triangle& t : triangles) {
+            // addFace takes any index (SimpleMesh.h:99-104): checked here, where it is followed
+            if (t.idx0 >= vertices.size() || t.idx1 >= vertices.size() || t.idx2 >= vertices.size())
+                throw std::out_of_range("SimpleMesh: a face names a vertex the mesh does not have");
             const float* a = vertices[t.idx0].position; const float* b = vertices[t.idx1].position; const float* c = vertices[t.idx2].position;
             out.emplace_back(Vector3f{ a[0], a[1], a[2] }, Vector3f{ b[0], b[1], b[2] }, Vector3f{ c[0], c[1], c[2] });
         }

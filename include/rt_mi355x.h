@@ -366,14 +366,17 @@ void     rt_mesh_transform(rt_mesh* mesh, const float rotation_rowmajor[9],
 /* positions: n*4 floats (xyzw); colors: n*4 floats; indices: n*3 uint32. */
 void     rt_mesh_copy_vertices(const rt_mesh* mesh, float* positions_xyzw, float* colors_rgba);
 void     rt_mesh_copy_indices(const rt_mesh* mesh, uint32_t* indices);
-/* Writes rt_mesh_triangle_count() SimpleTriangles. */
-void     rt_mesh_to_triangles(const rt_mesh* mesh, rt_triangle* out);
+/* Writes rt_mesh_triangle_count() SimpleTriangles.  RT_ERR_INVALID_ARG (nothing written) when a face names a vertex
+ * the mesh does not have: rt_mesh_add_face takes any index, as SimpleMesh::addFace does, so a host may add faces
+ * before their vertices — the indices are checked here, where they are followed. */
+int      rt_mesh_to_triangles(const rt_mesh* mesh, rt_triangle* out);
 /* Writes rt_mesh_triangle_count() x rgb: the mean of each face's three vertex colours
  * (Vertex::color, SimpleMesh.h:27), for rt_upload_triangle_colors.  No counterpart in the
- * reference, whose shader colours every triangle red. */
-void     rt_mesh_triangle_colors(const rt_mesh* mesh, float* rgb);
+ * reference, whose shader colours every triangle red.  RT_ERR_INVALID_ARG as for rt_mesh_to_triangles. */
+int      rt_mesh_triangle_colors(const rt_mesh* mesh, float* rgb);
 /* The rest of SimpleMesh: an empty mesh (:42), clear :47-50, addVertex :93-97, addFace
- * :99-104 (both return the new element's index), setColor :87-91, writeMesh :217-245 (a COFF
+ * :99-104 (both return the new element's index, 0xffffffff when memory runs out; addFace does not look at the
+ * indices), setColor :87-91, writeMesh :217-245 (a COFF
  * file; colours are written as int(colour), as there), joinMeshes :251-288 (pose1to2: 4x4
  * column-major applied to mesh1's positions, NULL = identity), sphere :293-317 (the
  * 12-vertex, 20-face icosahedron). */

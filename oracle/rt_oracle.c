@@ -525,12 +525,15 @@ static v3 shape_normal(const orc_params* prm, const orc_shape* s, v3 p)
         /* A fuzzy metal's direction left as written (scene.h:78) is not unit, and Sphere::hit, which assumes it is
          * (scene.h:115-123), then returns a point off the sphere: |v| is not the radius there. */
         if (prm->semantics == ORC_SEM_CPU && (prm->flags & ORC_FLAG_METAL_UNNORMALIZED)) return normalize(v);
-        /* The recipe: |v| is the radius to the rounding of the hit distance, so 1/radius is a first guess of
-         * 1/sqrt(v.v) that one Newton step y <- y (1.5 - (0.5 q y) y) takes to rounding level. */
-        float inv_r = 1.0f / s->m[0];
+        /* The recipe: |v| is the radius to the rounding of the hit distance, so 1/|radius| is a first guess of
+         * 1/sqrt(v.v) that one Newton step y <- y (1.5 - (0.5 q y) y) takes to rounding level.  The step's factor
+         * e = 1 - d (d: the guess's relative error) tells when that fails — a tiny sphere far away, whose hit
+         * point is off the sphere by more than 2^-12 of the radius: the full normalisation then. */
+        float inv_r = 1.0f / fabsf(s->m[0]);
         float q = dot(v, v);
         float t = (0.5f * q) * inv_r;
         float e = fmaf(-t, inv_r, 1.5f);
+        if (!(fabsf(e - 1.0f) <= 0x1p-12f)) return normalize(v);
         return vscale(v, inv_r * e);
     }
     if (s->type == 1) {

@@ -95,8 +95,8 @@ SIGNATURES = {
     "rt_mesh_transform": (None, [_vp, _fp, _fp]),
     "rt_mesh_copy_vertices": (None, [_vp, _vp, _vp]),
     "rt_mesh_copy_indices": (None, [_vp, _vp]),
-    "rt_mesh_to_triangles": (None, [_vp, _vp]),
-    "rt_mesh_triangle_colors": (None, [_vp, _vp]),
+    "rt_mesh_to_triangles": (_int, [_vp, _vp]),
+    "rt_mesh_triangle_colors": (_int, [_vp, _vp]),
     "rt_mesh_create": (_int, [C.POINTER(_vp)]),
     "rt_mesh_clear": (None, [_vp]),
     "rt_mesh_add_vertex": (_u32, [_vp, _fp, _fp]),

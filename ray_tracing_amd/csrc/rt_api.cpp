@@ -76,8 +76,10 @@ struct rt_ctx {
     uint32_t tile_cap = 0;               // tiles allocated for (the plan holds 2 * tile_cap entries)
     uint32_t order_tiles_x = 0, order_tiles_y = 0;   // tiling the plan is valid for (0 = none yet)
     uint32_t plan_units = 0;             // workgroups of the planned launch
+    uint32_t plan_max_slices = 1;        // the most slices a tile of that plan may have been cut into
 
     int compute_units = 0;
+    uint32_t lds_limit = rtd::LDS_WORKGROUP_MAX_BYTES;   // what a workgroup can have of a CU's LDS on this device (hipDeviceProp_t::sharedMemPerBlock, at most 160 KiB)
 
     // This device's copy of the library's static scratch (rt_render_noalloc), looked up once in rt_create.
     uint32_t* d_scratch = nullptr;
@@ -355,9 +357,9 @@ static int plan_blob(rt_ctx* ctx, BlobPlan& B)
     L.total_words = L.inv_off + (n_tris + 3u) / 4u;
     B.colors = !ctx->tri_colors.empty() && ctx->tri_colors.size() == 3u * (size_t)n_tris;
     const uint32_t wave_words = (n_tris || n_box) ? rtd::lds_wave_words(ctx->group_waves, false) : 0u;     // queues and slots of the spread tests
-    if ((size_t)(L.node_off[rtd::TREE_LEVELS - 1u] + (n_tris ? rtd::lds_wave_words(ctx->group_waves, true) : wave_words)) * 16u > rtd::LDS_WORKGROUP_MAX_BYTES)
-        return fail(ctx, RT_ERR_INVALID_ARG, "scene: %u shapes need more than the %u bytes of LDS a workgroup can have", n_shapes, rtd::LDS_WORKGROUP_MAX_BYTES);
-    if ((size_t)(staged_words + wave_words) * 16u <= rtd::LDS_MAX_BYTES && ctx->env_mesh_in_lds) { L.lds_words = staged_words; L.tri_in_lds = 1; }
+    if ((size_t)(L.node_off[rtd::TREE_LEVELS - 1u] + (n_tris ? rtd::lds_wave_words(ctx->group_waves, true) : wave_words)) * 16u > ctx->lds_limit)
+        return fail(ctx, RT_ERR_INVALID_ARG, "scene: %u shapes need more than the %u bytes of LDS a workgroup can have on this device", n_shapes, ctx->lds_limit);
+    if ((size_t)(staged_words + wave_words) * 16u <= std::min(rtd::LDS_MAX_BYTES, ctx->lds_limit) && ctx->env_mesh_in_lds) { L.lds_words = staged_words; L.tri_in_lds = 1; }
     else { L.lds_words = L.node_off[rtd::TREE_LEVELS - 1u]; L.tri_in_lds = 0; }     // the mesh and its tree stay in global memory
     // Per-triangle albedo: read only at a hit, so it stays in global memory behind everything else.
     if (B.colors) { L.tcol_off = L.total_words; L.total_words += n_tris; }
@@ -414,7 +416,7 @@ static int build_blob_impl(rt_ctx* ctx)
         as_u32(r1.f[3]) = (s.material.type & 0xffffu) | ((s.type & 0xffu) << 16) | (cls << 24);
         r2.f[0] = cls == 2u && ctx->cfg.semantics == RT_SEM_CPU ? s.material.data[1] : 0.0f;   // fuzz: the CPU tracer's metal only (scene.h:71,78)
         r2.f[1] = emit;
-        r2.f[2] = s.type == RT_SHAPE_CIRCLE ? 1.0f / scale : rcp_nr(scale);      // sphere: first guess of its normal's 1 / length; box: boxNormalAt's 1 / side
+        r2.f[2] = s.type == RT_SHAPE_CIRCLE ? 1.0f / std::fabs(scale) : rcp_nr(scale);      // sphere: first guess of its normal's 1 / length (the test squares the radius, so its sign means nothing: scene.h:118,131); box: boxNormalAt's 1 / side
         // A Box's sides along y and z: the shader's single side, or its own (RT_FLAG_BOX_SIDES).
         const bool own_sides = (ctx->cfg.flags & RT_FLAG_BOX_SIDES) != 0u;
         const float side_y = own_sides ? s.transformation[5] : scale, side_z = own_sides ? s.transformation[10] : scale;
@@ -528,6 +530,7 @@ int rt_create(rt_ctx** out, const rt_config* cfg)
     e = hipGetDeviceProperties(&prop, c.device);
     if (e != hipSuccess) { (void)hipFree(ctx->d_stats); delete ctx; return fail(nullptr, RT_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); }
     ctx->compute_units = prop.multiProcessorCount;
+    if (prop.sharedMemPerBlock > 0) ctx->lds_limit = (uint32_t)std::min<size_t>(prop.sharedMemPerBlock, rtd::LDS_WORKGROUP_MAX_BYTES);
     // This device's address of the library's static scratch (the device is current here); rt_render_noalloc uses it.
     e = rtd::scratch_for_device(c.device, &ctx->d_scratch);
     if (e != hipSuccess) { (void)hipFree(ctx->d_stats); delete ctx; return fail(nullptr, RT_ERR_HIP, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e)); }
@@ -814,15 +817,18 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         // The plan made from the last frame holds while the tiling stays the same; a new tiling starts from clean
         // costs.  A plan that cuts tiles into slices of the sample range (it then has more entries than tiles) is
         // dropped for a call of 2^24 samples or more, which the slices' arithmetic (spp * slice) does not hold.
+        // So is a plan whose slices this call's samples cannot fill (a plan of 16 slices made for 256 samples,
+        // then a preview of 4): most of its workgroups would start, stage the scene and find nothing to do.
         const bool have_plan = ctx->order_tiles_x == P.tiles_x && ctx->order_tiles_y == P.tiles_y && !ctx->env_no_tile_order &&
-                               (spp < (1u << 24) || ctx->plan_units == n_tiles);
+                               (ctx->plan_units == n_tiles || (spp < (1u << 24) && slices_allowed(ctx, spp) >= ctx->plan_max_slices));
         if (!have_plan) RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, sizeof(uint32_t) * n_tiles, ctx->stream));
         uint32_t plan_units = have_plan ? ctx->plan_units : n_tiles;
         int32_t* d_timeline = nullptr;
         if (timeline_host) {
             if (timeline_waves < 4u * plan_units) return fail(ctx, RT_ERR_INVALID_ARG, "timeline buffer holds %u waves, the launch has %u", timeline_waves, 4u * plan_units);
             RT_HIP(ctx, hipMalloc(&d_timeline, sizeof(int32_t) * 16u * plan_units));
-            RT_HIP(ctx, hipMemsetAsync(d_timeline, 0, sizeof(int32_t) * 16u * plan_units, ctx->stream));
+            const hipError_t me = hipMemsetAsync(d_timeline, 0, sizeof(int32_t) * 16u * plan_units, ctx->stream);
+            if (me != hipSuccess) { (void)hipFree(d_timeline); RT_HIP(ctx, me); }
         }
         const uint32_t launched = plan_units;
         rc = trace_frame(ctx, P, accum_ptr(ctx), stats ? 1 : 0, ctx->d_tile_cost, ctx->d_tile_order, have_plan,
@@ -837,6 +843,7 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         RT_HIP(ctx, le);
         ctx->order_tiles_x = P.tiles_x; ctx->order_tiles_y = P.tiles_y;
         ctx->plan_units = plan_units;
+        ctx->plan_max_slices = plan_units == n_tiles ? 1u : slices_allowed(ctx, spp);
     }
     ctx->accum_samples += spp;
     if (stats) {

@@ -287,29 +287,42 @@ void rt_mesh_copy_indices(const rt_mesh* mesh, uint32_t* indices)
     if (mesh && indices && !mesh->indices.empty()) memcpy(indices, mesh->indices.data(), mesh->indices.size() * sizeof(uint32_t));
 }
 
-// The loop of src/main.cpp:113-122.
-void rt_mesh_to_triangles(const rt_mesh* mesh, rt_triangle* out)
+// A face may name a vertex that does not exist (yet): addFace takes any index, as SimpleMesh::addFace does
+// (SimpleMesh.h:99-104).  The routines that follow the indices check them first.
+static bool faces_in_range(const rt_mesh* mesh)
 {
-    if (!mesh || !out) return;
+    const size_t nv = mesh->vertices.size();
+    for (uint32_t i : mesh->indices) if (i >= nv) return false;
+    return true;
+}
+
+// The loop of src/main.cpp:113-122.
+int rt_mesh_to_triangles(const rt_mesh* mesh, rt_triangle* out)
+{
+    if (!mesh || !out) return RT_ERR_INVALID_ARG;
+    if (!faces_in_range(mesh)) return RT_ERR_INVALID_ARG;
     for (size_t t = 0; t < mesh->indices.size() / 3; ++t) {
         const float* v0 = mesh->vertices[mesh->indices[3 * t]].position;
         const float* v1 = mesh->vertices[mesh->indices[3 * t + 1]].position;
         const float* v2 = mesh->vertices[mesh->indices[3 * t + 2]].position;
         rt_make_triangle(&out[t], v0, v1, v2);
     }
+    return RT_OK;
 }
 
 
 // Mean of the three vertex colours of each face (Vertex::color, SimpleMesh.h:27).
-void rt_mesh_triangle_colors(const rt_mesh* mesh, float* rgb)
+int rt_mesh_triangle_colors(const rt_mesh* mesh, float* rgb)
 {
-    if (!mesh || !rgb) return;
+    if (!mesh || !rgb) return RT_ERR_INVALID_ARG;
+    if (!faces_in_range(mesh)) return RT_ERR_INVALID_ARG;
     for (size_t t = 0; t < mesh->indices.size() / 3; ++t) {
         const float* c0 = mesh->vertices[mesh->indices[3 * t]].color;
         const float* c1 = mesh->vertices[mesh->indices[3 * t + 1]].color;
         const float* c2 = mesh->vertices[mesh->indices[3 * t + 2]].color;
         for (int k = 0; k < 3; ++k) rgb[3 * t + k] = ((c0[k] + c1[k]) + c2[k]) / 3.0f;
     }
+    return RT_OK;
 }
 
 int rt_mesh_create(rt_mesh** out)                                // SimpleMesh(), SimpleMesh.h:42
@@ -339,10 +352,6 @@ uint32_t rt_mesh_add_vertex(rt_mesh* mesh, const float position[4], const float 
 uint32_t rt_mesh_add_face(rt_mesh* mesh, uint32_t idx0, uint32_t idx1, uint32_t idx2)      // SimpleMesh.h:99-104
 {
     if (!mesh) return 0xffffffffu;
-    // rt_mesh_to_triangles and rt_mesh_triangle_colors index the vertices with these: a face may only name vertices
-    // that exist (the same rule rt_mesh_load applies to a file's faces).
-    const size_t nv = mesh->vertices.size();
-    if (idx0 >= nv || idx1 >= nv || idx2 >= nv) return 0xffffffffu;
     try {
         mesh->indices.reserve(mesh->indices.size() + 3u);
         mesh->indices.push_back(idx0); mesh->indices.push_back(idx1); mesh->indices.push_back(idx2);

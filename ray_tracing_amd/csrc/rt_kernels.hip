@@ -26,7 +26,7 @@
 //
 // Arithmetic: binary32 throughout, compiled with -ffp-contract=off.  Every
 // fused multiply-add is an explicit __builtin_fmaf; sqrt is correctly rounded
-// (v_sqrt_f32 plus a residual test); reciprocal square root and reciprocal are
+// (v_rsq_f32 plus one exact correction step, sqrt_rn below); reciprocal square root and reciprocal are
 // fixed Newton recipes; sin/cos a fixed polynomial.  No OCML function feeds
 // geometry.  With that, every value computed here can be reproduced bit for
 // bit by scalar IEEE-754 code on a CPU.
@@ -108,15 +108,25 @@ RT_DEV float rsqrt_nr(float q)
 }
 RT_DEV V3 normalize(V3 v) { return v * rsqrt_nr(dot(v, v)); }
 // normalize(p - centre) at a point of a sphere (scene.h:130-132, RayTracing.glsl:134-136): the length is the radius
-// to the rounding of the hit distance (relative d, 1e-7 .. 1e-5), so 1/radius — stored with the shape — is a first
+// to the rounding of the hit distance (relative d, 1e-7 .. 1e-5), so 1/|radius| — stored with the shape — is a first
 // guess that ONE Newton step y <- y * (1.5 - (0.5 q y) y) takes to 1.5 d^2 of 1/sqrt(q): four instructions for the
-// thirteen of the bit-trick guess and its three steps.
+// thirteen of the bit-trick guess and its three steps.  The step's own factor e = 1 - d tells how good the guess
+// was: where it is further than SPHERE_NORMAL_GUESS from 1 (a tiny sphere far away, whose hit point is off the
+// sphere by more than that share of the radius) the lane takes the full normalisation instead — a branch no lane of
+// an ordinary scene takes.
+constexpr float SPHERE_NORMAL_GUESS = 0x1p-12f;
 RT_DEV V3 sphere_normal(V3 v, float inv_radius)
 {
     const float q = dot(v, v);
     const float t = (0.5f * q) * inv_radius;
     const float e = fma_(-t, inv_radius, 1.5f);
-    return v * (inv_radius * e);
+    V3 n = v * (inv_radius * e);
+    const bool off = !(__builtin_fabsf(e - 1.0f) <= SPHERE_NORMAL_GUESS);
+    if (__any(off)) {
+        const float full = rsqrt_nr(q);
+        n = v3(off ? v.x * full : n.x, off ? v.y * full : n.y, off ? v.z * full : n.z);
+    }
+    return n;
 }
 // 1/x the same way: y <- y * (2 - x*y), three times (relative error <= 1.2e-7).
 // a / b of the shader's routines (RayTracing.glsl:145,161,181) is a * rcp_nr(b):
@@ -599,8 +609,11 @@ void trace_kernel(const TraceParams P,
     // workgroups sharing an entry.
     const uint32_t q = blockIdx.x * P.group_waves + (tid >> 6);
     const uint32_t unit = (q >> 2) < P.plan_entries ? (tile_order ? tile_order[q >> 2] : (n_tiles - 1u - (q >> 2))) : WORK_NONE;
-    // Workgroups of four waves hold one entry; larger ones may hold entries with and without work.
-    if (P.group_waves <= 4u ? unit == WORK_NONE : __syncthreads_count(unit != WORK_NONE) == 0) return;
+    // Workgroups of one, two or four waves lie inside one entry; those of three or of more than four may hold
+    // entries with and without work, and leave only when none of their waves has any (every wave that stays takes
+    // part in the staging loop and the barrier below).
+    const bool one_entry = P.group_waves <= 4u && P.group_waves != 3u;
+    if (one_entry ? unit == WORK_NONE : __syncthreads_count(unit != WORK_NONE) == 0) return;
     for (uint32_t i = tid; i < P.scene.lds_words; i += blockDim.x) lds[i] = blob[i];
     __syncthreads();
     if (unit == WORK_NONE) return;                       // uniform over the wave; no barrier follows

@@ -243,7 +243,8 @@ class SimpleMesh:
         """The loop of src/main.cpp:113-122 -> structured array of SimpleTriangle."""
         n = lib.rt_mesh_triangle_count(self._h)
         out = np.zeros(n, dtype=TRIANGLE_DTYPE)
-        lib.rt_mesh_to_triangles(self._h, out.ctypes.data)
+        if lib.rt_mesh_to_triangles(self._h, out.ctypes.data) != 0:
+            raise IndexError("SimpleMesh: a face names a vertex the mesh does not have")
         return out
 
     def triangleColors(self):
@@ -251,7 +252,8 @@ class SimpleMesh:
         SimpleMesh.h:170-183; the reference's shader ignores them, RayTracing.glsl:275)."""
         n = lib.rt_mesh_triangle_count(self._h)
         out = np.zeros((n, 3), dtype=np.float32)
-        lib.rt_mesh_triangle_colors(self._h, out.ctypes.data)
+        if lib.rt_mesh_triangle_colors(self._h, out.ctypes.data) != 0:
+            raise IndexError("SimpleMesh: a face names a vertex the mesh does not have")
         return out
 
 

@@ -92,7 +92,8 @@ def reduce_framebuffer(accum_words, semantics, dst=0, group=None, async_op=False
     t = accum_view(accum_words, semantics)
     if t.is_cuda and dist.get_backend(group) == "gloo":
         # Rehearsals only (ranks sharing one GPU, gloo between them): summed through host memory and completed
-        # here — gloo's own handling of device tensors was seen to stall on the second 33 MB frame.
+        # here, whatever async_op says (the call blocks on the copy to the host) — gloo's own handling of device
+        # tensors was seen to stall on the second 33 MB frame.
         host = t.cpu()
         dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
         if dist.get_rank(group) == dst:
@@ -116,29 +117,75 @@ class _BandGather:
         return True
 
 
+class _BandBuffers:
+    """What one accumulator's band gathers need besides the accumulator itself, made once and kept: the row index list
+    of every rank (on the accumulator's device), the send buffer, and on the destination the receive buffers."""
+
+    def __init__(self, accum_words, world, rank, band_rows, dst, on_host):
+        height = accum_words.shape[0]
+        dev = accum_words.device
+        self.rows = [owned_rows(height, r, world, band_rows).to(dev) for r in range(world)]
+        most = max(len(r) for r in self.rows)
+        self.send = accum_words.new_zeros((most,) + tuple(accum_words.shape[1:]))
+        # rehearsals (ranks sharing one GPU, gloo between them): gloo gathers host tensors only
+        self.send_host = torch.zeros_like(self.send, device="cpu") if on_host else None
+        wire = self.send_host if on_host else self.send
+        self.recv = [torch.empty_like(wire) for _ in range(world)] if rank == dst else None
+        self.back = [torch.empty_like(self.send) for _ in range(world)] if (on_host and rank == dst) else None
+
+
+_band_buffers = {}
+band_buffer_builds = 0          # how often a _BandBuffers was made (tests: a second frame makes none)
+
+
+def _buffers_for(accum_words, world, rank, band_rows, dst, on_host, group):
+    global band_buffer_builds
+    key = (accum_words.data_ptr(), tuple(accum_words.shape), accum_words.dtype, str(accum_words.device), world, rank, band_rows, dst,
+           on_host, id(group))
+    b = _band_buffers.get(key)
+    if b is None:
+        if len(_band_buffers) >= 16:                     # accumulators come and go (bench.py measures two splits)
+            _band_buffers.clear()
+        b = _band_buffers[key] = _BandBuffers(accum_words, world, rank, band_rows, dst, on_host)
+        band_buffer_builds += 1
+    return b
+
+
 def gather_bands(accum_words, shard, dst=0, group=None, async_op=False, always=False):
     """The exchange of the `rows` split: every rank sends the bands it rendered to rank `dst`, which puts them into
     its own accumulator (in place).  A rank's bands are copied into one contiguous send buffer (padded to the
     largest rank's row count, so that all contributions have one size), one gather moves them, and `dst` writes
     rank r's rows back with the same row index list.  Nothing is summed: the frame is bit-identical to a single-GPU
-    render whatever the sums' type."""
+    render whatever the sums' type.
+
+    The index lists and the send / receive buffers belong to the accumulator (keyed by its address) and are made by
+    its first gather only: a frame's exchange is one index_select into the send buffer, the gather, and on `dst`
+    world - 1 index_copy_ — no allocation, no host-to-device copy.  Two accumulators used in turn have two sets, so
+    a gather still in flight is not overwritten by the next frame's.  With gloo on device tensors (rehearsals) the
+    bands go through host buffers and the call completes before it returns, whatever async_op says."""
     if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not always):
         return None
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    height = accum_words.shape[0]
-    rows = [owned_rows(height, r, world, shard.band_rows).to(accum_words.device) for r in range(world)]
-    most = max(len(r) for r in rows)
-    send = accum_words.new_zeros((most,) + tuple(accum_words.shape[1:]))
-    send[:len(rows[rank])] = accum_words.index_select(0, rows[rank])
-    on_host = accum_words.is_cuda and dist.get_backend(group) == "gloo"      # rehearsals: gloo gathers host tensors only
-    buf = send.cpu() if on_host else send
-    recv = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
-    work = dist.gather(buf, recv, dst=dst, group=group, async_op=async_op)
+    on_host = accum_words.is_cuda and dist.get_backend(group) == "gloo"
+    b = _buffers_for(accum_words, world, rank, shard.band_rows, dst, on_host, group)
+    n_own = len(b.rows[rank])
+    if n_own:
+        torch.index_select(accum_words, 0, b.rows[rank], out=b.send[:n_own])
+    if on_host:
+        b.send_host.copy_(b.send)
+        dist.gather(b.send_host, b.recv, dst=dst, group=group)
+        if rank == dst:
+            for r in range(world):
+                if r != dst and len(b.rows[r]):
+                    b.back[r].copy_(b.recv[r])
+                    accum_words.index_copy_(0, b.rows[r], b.back[r][:len(b.rows[r])])
+        return _BandGather(None, None) if async_op else None
+    work = dist.gather(b.send, b.recv, dst=dst, group=group, async_op=async_op)
 
     def place():
         for r in range(world):
-            if r != dst:
-                accum_words.index_copy_(0, rows[r], recv[r][:len(rows[r])].to(accum_words.device))
+            if r != dst and len(b.rows[r]):
+                accum_words.index_copy_(0, b.rows[r], b.recv[r][:len(b.rows[r])])
 
     handle = _BandGather(work if async_op else None, place if rank == dst else None)
     if async_op:

@@ -26,6 +26,7 @@ def cases(scenes, full=False):
         "c3": (scenes.config3(width=160, height=90, spp=8), 0),
         "c4": (scenes.config4(width=192, height=108, spp=16), 0),
         "c5": (scenes.config5(width=128, height=128, spp=8), 0),
+        "c5e": (scenes.config5_enclosed(width=128, height=128, spp=8), 0),
         "cpu_tracer": (scenes.config_cpu_tracer(width=160, height=160), 5),
     }
     if full:
@@ -52,15 +53,33 @@ def _grazes(orc, cfg, p, x, y, sample, index):
     return abs(miss / r - 1.0) < 1e-4
 
 
-def study(orc, cfg, grid_n=0, trace_samples=4):
-    """-> dict of agreement figures between the two arithmetics for one scene."""
+class RecipeOracle:
+    """`ours` of study(): the oracle in the arithmetic the HIP kernels repeat bit for bit."""
+
+    def __init__(self, orc, cfg, grid_n=0):
+        self.orc, self.cfg, self.p = orc, cfg, oracle_params(orc, cfg, grid_n=grid_n)
+
+    def trace(self, sample):
+        return self.orc.trace(self.cfg.shapes, self.cfg.triangles, self.cfg.camera, self.p, sample)[0]
+
+    def render(self):
+        return self.orc.render(self.cfg.shapes, self.cfg.triangles, self.cfg.camera, self.p)[0]
+
+
+def study(orc, cfg, grid_n=0, trace_samples=4, ours=None):
+    """-> dict of agreement figures for one scene between `ours` — an object with trace(sample) -> hit indices
+    [h, w, depth] and render() -> accumulator words; default: the oracle's recipe arithmetic, and the GPU tests pass
+    the HIP renderer — and the oracle in the reference's literal arithmetic."""
+    with_sampler_study = ours is None
     pr = oracle_params(orc, cfg, grid_n=grid_n)
+    if ours is None:
+        ours = RecipeOracle(orc, cfg, grid_n)
     pl = oracle_params(orc, cfg, grid_n=grid_n, arith=orc.ARITH_LITERAL)
     cube_ids = {i for i in range(len(cfg.shapes)) if int(cfg.shapes[i]["type"]) == 3}
     first_n = first_diff = seg_n = seg_same = 0
     unexplained, classes = [], {"cube_exact_surface_test": 0, "sphere_silhouette": 0}
     for s in range(min(trace_samples, cfg.spp)):
-        hr, _ = orc.trace(cfg.shapes, cfg.triangles, cfg.camera, pr, s)
+        hr = ours.trace(s)
         hl, _ = orc.trace(cfg.shapes, cfg.triangles, cfg.camera, pl, s)
         d = hr[..., 0] != hl[..., 0]
         first_n += d.size
@@ -77,7 +96,7 @@ def study(orc, cfg, grid_n=0, trace_samples=4):
         seg_n += int(live.sum())
         seg_same += int(((hr == hl) & live).sum())
     gamma = cfg.semantics == 0
-    ar, _ = orc.render(cfg.shapes, cfg.triangles, cfg.camera, pr)
+    ar = ours.render()
     al, _ = orc.render(cfg.shapes, cfg.triangles, cfg.camera, pl)
     a = orc.resolve(ar, cfg.spp, cfg.semantics, gamma_sqrt=gamma)[..., :3].astype(np.float64)
     b = orc.resolve(al, cfg.spp, cfg.semantics, gamma_sqrt=gamma)[..., :3].astype(np.float64)
@@ -92,7 +111,7 @@ def study(orc, cfg, grid_n=0, trace_samples=4):
         "image_psnr_db": _psnr(a, b),                  # None: the two frames are identical
         "image_mean_relative_difference": round(abs(float(a.mean()) - float(b.mean())) / float(a.mean()), 6),
     }
-    if cfg.semantics == 0:
+    if cfg.semantics == 0 and with_sampler_study:
         # utils.h:45 as written — three normal deviates, normalised — maps the draws to directions differently, so
         # frames agree only statistically; the same frame with another seed gives the noise floor to read it against.
         pg = oracle_params(orc, cfg, grid_n=grid_n, arith=orc.ARITH_LITERAL, unit_sampler=orc.UNIT_GAUSS)
@@ -107,3 +126,23 @@ def study(orc, cfg, grid_n=0, trace_samples=4):
             "noise_floor_other_seed_psnr_db": _psnr(a, e),
             "noise_floor_other_seed_mean_relative_difference": round(abs(float(a.mean()) - float(e.mean())) / float(a.mean()), 6)}
     return out
+
+
+def no_worse_than(figures, frozen):
+    """-> list of complaints: where `figures` (a study() result) are further from the literal arithmetic than the
+    frozen bounds of tests/golden/literal_bounds_frozen.json allow."""
+    bad = []
+    if figures["first_hit_differences_unexplained"]:
+        bad.append(f"first hits differ away from a silhouette or the Cube: {figures['first_hit_differences_unexplained'][:3]}")
+    if figures["first_hits_differing"] > frozen["first_hits_differing_max"]:
+        bad.append(f"first hits differing {figures['first_hits_differing']} > {frozen['first_hits_differing_max']}")
+    if figures["segment_hit_agreement_percent"] < frozen["segment_hit_agreement_percent_min"] - 1e-4:
+        bad.append(f"segments agreeing {figures['segment_hit_agreement_percent']} % < {frozen['segment_hit_agreement_percent_min']} %")
+    psnr, floor = figures["image_psnr_db"], frozen["image_psnr_db_min"]          # None: identical frames
+    if floor is None and psnr is not None:
+        bad.append(f"frames were identical, PSNR now {psnr} dB")
+    if floor is not None and psnr is not None and psnr < floor - 0.01:
+        bad.append(f"PSNR {psnr} dB < {floor} dB")
+    if figures["image_max_abs"] > frozen["image_max_abs_max"] + 1e-6:
+        bad.append(f"max-abs {figures['image_max_abs']} > {frozen['image_max_abs_max']}")
+    return bad

@@ -80,9 +80,15 @@ int main(int argc, char** argv)
     const float p0[4] = { 0, 0, 0, 1 }, p1[4] = { 1, 0, 0, 1 }, p2[4] = { 0, 1, 0, 1 };
     rt_mesh_add_vertex(hand, p0, white); rt_mesh_add_vertex(hand, p1, white); rt_mesh_add_vertex(hand, p2, white);
     CHECK(rt_mesh_add_face(hand, 0, 1, 2) == 0);
-    CHECK(rt_mesh_add_face(hand, 0, 1, 99) == 0xffffffffu);                    // an index without a vertex is refused
-    std::vector<rt_triangle> one(rt_mesh_triangle_count(hand));
-    rt_mesh_to_triangles(hand, one.data());
+    CHECK(rt_mesh_add_face(hand, 0, 1, 3) == 1);                               // a face before its vertex: taken, as SimpleMesh::addFace takes it
+    std::vector<rt_triangle> two(rt_mesh_triangle_count(hand));
+    std::vector<float> two_rgb(3 * two.size());
+    CHECK(rt_mesh_to_triangles(hand, two.data()) == RT_ERR_INVALID_ARG);       // ... and refused where the indices are followed
+    CHECK(rt_mesh_triangle_colors(hand, two_rgb.data()) == RT_ERR_INVALID_ARG);
+    const float p3[4] = { 1, 1, 0, 1 };
+    rt_mesh_add_vertex(hand, p3, white);
+    CHECK(rt_mesh_to_triangles(hand, two.data()) == RT_OK);
+    CHECK(rt_mesh_triangle_colors(hand, two_rgb.data()) == RT_OK);
     rt_mesh_clear(hand);
     // malformed files: each must be refused (or read) without touching memory it does not own
     const char* bad[] = {

@@ -48,6 +48,53 @@ def check_config(rta, orc, cfg, trace_samples=(0,), grid_n=0):
     return stats
 
 
+class _HipFrames:
+    """`ours` of literal_study.study(): hit indices and accumulator words of the HIP renderer."""
+
+    def __init__(self, rta, cfg, grid_n):
+        self.rt, self.cfg, self.grid_n = rta.scenes.make_renderer(cfg), cfg, grid_n
+
+    def trace(self, sample):
+        c = self.cfg
+        return self.rt.traceDebug(c.width, c.height, c.max_depth, c.seed, sample, grid_n=self.grid_n)[0]
+
+    def render(self):
+        import torch
+        c = self.cfg
+        acc = torch.zeros(c.height, c.width, 4, dtype=torch.int32, device="cuda")
+        self.rt.bindAccum(acc.data_ptr(), c.width, c.height)
+        self.rt.render(c.width, c.height, c.spp, c.max_depth, c.seed, grid_n=self.grid_n)
+        torch.cuda.synchronize()
+        self.rt.bindAccum(None, 0, 0)
+        return acc.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5", "c5e", "cpu_tracer"])
+def test_hip_frame_within_the_literal_bound(rta, orc, name):
+    """The HIP frame and its followed hit indices against the oracle in the reference's LITERAL arithmetic (no FMA,
+    IEEE divide, v / sqrt(v.v), libm sine and cosine, Sphere::hit's distance in double) — not against the recipes the
+    kernels share with the oracle: first hits differing, segments hitting the same primitive, PSNR and max-abs of the
+    resolved frame must be no worse than the frozen floor of tests/golden/literal_bounds_frozen.json, and equal to
+    the committed report of the recipe arithmetic (the kernels repeat it bit for bit)."""
+    import json
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    from literal_study import cases, no_worse_than, study
+    cfg, grid_n = cases(rta.scenes)[name]
+    ours = _HipFrames(rta, cfg, grid_n)
+    try:
+        r = study(orc, cfg, grid_n, ours=ours)
+    finally:
+        ours.rt.close()
+    worse = no_worse_than(r, json.load(open(os.path.join(here, "golden", "literal_bounds_frozen.json")))["configs"][name])
+    assert not worse, f"{name}: {worse}"
+    want = json.load(open(os.path.join(here, "golden", "literal_vs_recipe.json")))["configs"][name]
+    for k in ("first_hits_differing", "segment_hit_agreement_percent", "image_psnr_db", "image_max_abs"):
+        assert r[k] == want[k], (k, r[k], want[k])
+
+
 def test_config1_cpu_sphere_scene(rta, orc):
     """The CPU-runnable configuration at full size: 512x512, 16 spp, depth 4."""
     st = check_config(rta, orc, rta.scenes.config1(), trace_samples=(0, 7, 15))
@@ -233,7 +280,7 @@ def test_converter_running_mean(rta, orc):
 
 def test_first_frame_of_a_fresh_context_equals_the_oracle(rta, orc):
     """A one-shot render (no earlier frame to learn a plan from) of 64+ samples per pixel splits itself into a
-    16-sample probe, a plan and the rest; a short one runs in the built-in order.  Same words either way."""
+    probe of its first 8 samples, a plan and the rest; a short one runs in the built-in order.  Same words either way."""
     for sem in (0, 1):
         cfg = rta.scenes.config3(width=211, height=123, spp=80, max_depth=6)
         cfg.semantics = sem

@@ -166,6 +166,13 @@ def test_mesh_write_then_load(rta, tmp_path):
     m.addVertex((0, 0.25, 0, 1), (0, 0, 255, 255))
     m.addVertex((float("nan"), 0, 0, 1), (9, 9, 9, 9))                  # :229-233: non-finite -> zeros
     assert m.addFace(0, 1, 2) == 0 and m.addFace(2, 1, 0) == 1
+    early = rta.SimpleMesh()                                           # a face before its vertices, as SimpleMesh::addFace allows (:99-104)
+    assert early.addFace(0, 1, 2) == 0
+    with pytest.raises(IndexError):
+        early.toSimpleTriangles()                                      # checked where the indices are followed
+    for p in ((0, 0, 0, 1), (1, 0, 0, 1), (0, 1, 0, 1)):
+        early.addVertex(p)
+    assert len(early.toSimpleTriangles()) == 1 and early.triangleColors().shape == (1, 3)
     path = tmp_path / "out.off"
     assert m.writeMesh(path)
     assert path.read_text().split("\n") == ["COFF", "4 2 0", "0 0 0 1 0 0 1", "1.5 0 0 0 2 0 1", "0 0.25 0 0 0 255 255",

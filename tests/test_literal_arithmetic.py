@@ -4,18 +4,21 @@ image (max-abs and PSNR).  Runs on the CPU (both arithmetics live in the oracle)
 
 Stated bound, checked here: first hits identical except where the reference's own test is decided by the last bit
 (the Cube's `== 0.5`, a sphere's silhouette); >= 99.9 % of all ray segments hit the same primitive (99.5 % with the
-Cube in the scene); PSNR of the resolved frame >= 50 dB (>= 40 dB with the Cube).  tests/golden/literal_vs_recipe.json
-holds the figures (tools/literal_report.py writes it).
+Cube in the scene; 98.5 % in the enclosed room, whose paths are 14 segments long and differ from their first changed
+hit to their end); PSNR of the resolved frame >= 50 dB (>= 40 dB with the Cube).  tests/golden/literal_vs_recipe.json
+holds the figures (tools/literal_report.py writes it); tests/golden/literal_bounds_frozen.json holds the floor under
+them, which no later change of a recipe may pass (it is not regenerated).
 """
 import json
 import os
 
 import pytest
 
-from literal_study import cases, study
+from literal_study import cases, no_worse_than, study
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPORT = os.path.join(HERE, "golden", "literal_vs_recipe.json")
+FROZEN = os.path.join(HERE, "golden", "literal_bounds_frozen.json")
 
 
 @pytest.fixture(scope="module")
@@ -23,15 +26,18 @@ def report():
     return json.load(open(REPORT))
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5", "cpu_tracer", "c1_full"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5", "c5e", "cpu_tracer", "c1_full"])
 def test_recipes_against_literal_arithmetic(rta, orc, report, name):
     cfg, grid_n = cases(rta.scenes, full=True)[name]
     r = study(orc, cfg, grid_n)
     has_cube = name == "cpu_tracer"
+    # A recipe and the oracle that defines it change together, and the report with them: the frozen floor does not.
+    worse = no_worse_than(r, json.load(open(FROZEN))["configs"][name])
+    assert not worse, f"{name}: the recipes moved away from the reference's literal arithmetic: {worse}"
     assert not r["first_hit_differences_unexplained"], r["first_hit_differences_unexplained"][:5]
     if not has_cube:
         assert r["first_hits_differing"] <= 1e-4 * r["first_hits_compared"]
-    assert r["segment_hit_agreement_percent"] >= (99.5 if has_cube else 99.9)
+    assert r["segment_hit_agreement_percent"] >= (99.5 if has_cube else 98.5 if name == "c5e" else 99.9)
     assert r["image_psnr_db"] is None or r["image_psnr_db"] >= (40.0 if has_cube else 50.0)
     assert r["image_mean_relative_difference"] <= 2e-3
     g = r.get("normalised_gaussian_sampler")

@@ -103,3 +103,51 @@ def test_exchange_bytes():
     assert parallel.exchange_bytes("rows", 1920, 1080, 8) == frame // 8
     assert parallel.exchange_bytes("samples", 1920, 1080, 8) == frame * 7 // 8
     assert parallel.exchange_bytes("rows", 1920, 1080, 1) == 0
+
+
+def _steady_gather_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ray_tracing_amd import parallel
+    height, band = 70, 16
+    shard = parallel.plan("rows", rank, world, 1, band_rows=band)
+    # two accumulators used in turn, as bench.py's frames use them
+    frames = [torch.zeros((height, 3, 4), dtype=torch.int32) for _ in range(2)]
+    made, ptrs, allocs = [], [], []
+    real_empty_like, real_arange = torch.empty_like, torch.arange
+    counted = {"n": 0}
+
+    def counting(fn):
+        def wrapped(*a, **k):
+            counted["n"] += 1
+            return fn(*a, **k)
+        return wrapped
+    for k in range(6):
+        t = frames[k % 2]
+        t.fill_(-7)
+        t[parallel.owned_rows(height, rank, world, band)] = 100 * k + rank + 1
+        if k >= 2:                                              # from the third frame on both accumulators have their buffers
+            torch.empty_like, torch.arange = counting(real_empty_like), counting(real_arange)
+        h = parallel.gather_bands(t, shard, async_op=True)
+        h.wait()
+        torch.empty_like, torch.arange = real_empty_like, real_arange
+        made.append(parallel.band_buffer_builds)
+        ptrs.append(tuple(b.send.data_ptr() for b in parallel._band_buffers.values()))
+        if rank == 0:
+            allocs.append(t[:, 0, 0].clone().numpy())
+    assert made == [1, 2, 2, 2, 2, 2], made                    # one set of buffers per accumulator, then none
+    assert ptrs[1] == ptrs[5] and len(ptrs[5]) == 2            # ... and the same memory every frame
+    assert counted["n"] == 0, counted                           # no index list rebuilt, no receive buffer allocated
+    if rank == 0:
+        np.save(out_path, np.stack(allocs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_band_gather_allocates_nothing_after_its_first_frame(tmp_path):
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_steady_gather_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)                                         # [frame, row]
+    for k in range(6):
+        np.testing.assert_array_equal(got[k], 100 * k + (np.arange(70) // 16) % 2 + 1)
