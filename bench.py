@@ -129,8 +129,10 @@ def cpu_baseline(cfg, target_seconds=12.0, gpu_render=None):
     accumulator words): the PSNR of the headline metric."""
     from oracle import oracle as orc
     threads = host_threads()
+    # the arithmetic the kernels repeat bit for bit: the recipes, or under RT_FLAG_LITERAL_GEOMETRY the literal geometry
+    arith = orc.ARITH_LITERAL_GEOMETRY if cfg.flags & 8 else orc.ARITH_RECIPE
     p = orc.params(cfg.width, cfg.height, 1, cfg.max_depth, seed=cfg.seed, semantics=cfg.semantics,
-                   sample_mode=cfg.sample_mode, flags=cfg.flags, triangle_albedo=cfg.triangle_albedo, threads=threads)
+                   sample_mode=cfg.sample_mode, flags=cfg.flags, triangle_albedo=cfg.triangle_albedo, threads=threads, arith=arith)
     t0 = time.perf_counter()
     orc.render(cfg.shapes, cfg.triangles, cfg.camera, p)
     t1 = time.perf_counter() - t0
@@ -144,11 +146,12 @@ def cpu_baseline(cfg, target_seconds=12.0, gpu_render=None):
     n = cfg.width * cfg.height * spp * frames
     out = {"value": round(n / dt / 1e6, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
            "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
+           "flags": "gcc -O2 -std=c11 -ffp-contract=off -fno-fast-math -mfma -mavx2 -fopenmp (oracle/Makefile; not -march=native: the library is built on another machine than it runs on)",
            "sample": f"{frames} frame(s) of {cfg.width}x{cfg.height}, {spp} of {cfg.spp} spp, depth {cfg.max_depth}, "
                      f"same scene and seed; {dt:.1f} s on {threads} threads"}
     # The reference's own loop, std::for_each(par_unseq) (rayTracer.h:81), runs on one thread without TBB: one thread too.
     p1 = orc.params(cfg.width, cfg.height, max(1, spp * frames // (4 * threads)), cfg.max_depth, seed=cfg.seed, semantics=cfg.semantics,
-                    sample_mode=cfg.sample_mode, flags=cfg.flags, triangle_albedo=cfg.triangle_albedo, threads=1)
+                    sample_mode=cfg.sample_mode, flags=cfg.flags, triangle_albedo=cfg.triangle_albedo, threads=1, arith=arith)
     t0 = time.perf_counter()
     orc.render(cfg.shapes, cfg.triangles, cfg.camera, p1)
     dt1 = time.perf_counter() - t0
@@ -188,6 +191,7 @@ def main():
     ap.add_argument("--width", type=int, default=0, help="override the frame width (experiments)")
     ap.add_argument("--height", type=int, default=0, help="override the frame height (experiments)")
     ap.add_argument("--semantics", type=int, default=-1, choices=[-1, 0, 1], help="override the rule set (experiments): 0 CPU tracer, 1 shader")
+    ap.add_argument("--flags", type=int, default=0, help="rt_flags to add to the configuration's (experiments): 8 = RT_FLAG_LITERAL_GEOMETRY")
     ap.add_argument("--mesh", default="", help="c3 only: the mesh file under ray_tracing_amd/data (default Bunny-LowPoly.off; bunny.off has 4 968 triangles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="one GPU: frames in flight, each on its own context and stream (1: one after the other)")
@@ -203,7 +207,7 @@ def main():
     if args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.counters_child and not args.no_live_counters and not under_profiler:
         cfg_argv = ["--config", args.config] + (["--mesh", args.mesh] if args.mesh else []) + (["--spp", str(args.spp)] if args.spp else []) + \
                    (["--width", str(args.width), "--height", str(args.height)] if args.width and args.height else []) + \
-                   (["--semantics", str(args.semantics)] if args.semantics >= 0 else [])
+                   (["--semantics", str(args.semantics)] if args.semantics >= 0 else []) + (["--flags", str(args.flags)] if args.flags else [])
         live = live_counters(cfg_argv)
 
     import torch
@@ -245,6 +249,7 @@ def main():
         cfg.spp = args.spp
     if args.semantics >= 0:
         cfg.semantics = args.semantics
+    cfg.flags |= args.flags
     # Frames in flight.  One GPU: consecutive frames alternate between --streams contexts, each with its own
     # accumulator and HIP stream, so that the ramp and tail of one frame's launch are filled by the next frame's
     # (a progressive renderer queues its frames the same way).  Several GPUs: two accumulators on one stream, so that

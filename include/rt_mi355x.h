@@ -107,7 +107,16 @@ enum rt_flags {
     /* randomUnitVector() as the CPU tracer writes it (src/utils.h:45): three normal deviates, normalised
      * (Box-Muller on four draws per event), instead of the direct sphere point that has the same
      * distribution and is the default.  RT_SEM_CPU with RT_RNG_HASH only. */
-    RT_FLAG_UNIT_GAUSS         = 1u << 2
+    RT_FLAG_UNIT_GAUSS         = 1u << 2,
+    /* The CPU tracer's geometry in the arithmetic its source text has when a C++ compiler evaluates it without
+     * contraction: Sphere::hit, normalAt, the Ray constructor, Ray::at and reflect (src/cpu_version/scene.h:14-23,
+     * 115-132; src/utils.h:62-64) with every product and sum rounded on its own, normalized() as v / sqrt(v.v)
+     * with the IEEE root and quotient, and the hit distance computed, compared and windowed as the double that
+     * HitRecord::t is (scene.h:34,123,237).  By default those lines are evaluated with fused multiply-adds and
+     * Newton reciprocal roots, which moves a hit on a silhouette now and then.  The samplers keep their
+     * polynomial either way.  RT_SEM_CPU with RT_RNG_HASH, spheres and Cubes only (a scene with Boxes or
+     * triangles is refused), not together with RT_FLAG_UNIT_GAUSS. */
+    RT_FLAG_LITERAL_GEOMETRY   = 1u << 3
 };
 
 /* Which stream feeds the random draws. */

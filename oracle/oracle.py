@@ -18,7 +18,8 @@ COLOR_AS_WRITTEN, COLOR_FORWARD = 0, 1
 UNIT_DIRECT, UNIT_GAUSS = 0, 1
 RNG_HASH, RNG_GLSL = 0, 1
 FLAG_METAL_UNNORMALIZED, FLAG_BOX_SIDES, FLAG_UNIT_GAUSS = 1, 2, 4
-ARITH_RECIPE, ARITH_LITERAL = 0, 1
+FLAG_LITERAL_GEOMETRY = 8          # the renderer's flag of that value: the oracle ignores it and takes `arith` instead
+ARITH_RECIPE, ARITH_LITERAL, ARITH_LITERAL_GEOMETRY = 0, 1, 2
 
 
 class Params(C.Structure):

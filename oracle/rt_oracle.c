@@ -41,7 +41,12 @@ typedef struct { float x, y, z; } v3;
  * is a double and the unqualified sqrt of scene.h:123 is ::sqrt(double)).  It exists to measure how far the
  * recipes are from the text; nothing is compared bit for bit with it.  The flag belongs to the calling thread. */
 static __thread int t_lit __attribute__((tls_model("initial-exec"))) = 0;
-void orc_set_arith(int arith) { t_lit = arith == ORC_ARITH_LITERAL; }
+/* ORC_ARITH_LITERAL_GEOMETRY: the literal arithmetic for everything but the samplers, which keep their recipe (the
+ * polynomial sine and cosine, the fused z and r of the sphere point) — what the HIP kernels compute under
+ * RT_FLAG_LITERAL_GEOMETRY, bit for bit. */
+static __thread int t_poly __attribute__((tls_model("initial-exec"))) = 0;
+static inline void set_arith(uint32_t arith) { t_lit = arith != ORC_ARITH_RECIPE; t_poly = arith == ORC_ARITH_LITERAL_GEOMETRY; }
+void orc_set_arith(int arith) { set_arith((uint32_t)arith); }
 /* a*b + c: fused in the recipe arithmetic, two roundings in the literal one */
 static inline float lfma(float a, float b, float c) { return t_lit ? a * b + c : fmaf(a, b, c); }
 
@@ -198,7 +203,7 @@ void orc_glsl_seed(uint64_t seed, uint32_t width, uint32_t height, uint32_t gx, 
  * part of utils.h:45. */
 void orc_sincos2pi(float u, float* c_out, float* s_out)
 {
-    if (t_lit) {                                           /* angle = random() * 2 * pi; cos(angle), sin(angle)   glsl:66,69-70 */
+    if (t_lit && !t_poly) {                                /* angle = random() * 2 * pi; cos(angle), sin(angle)   glsl:66,69-70 */
         float angle = (u * 2.0f) * 3.14159265358979323846f;
         *c_out = cosf(angle); *s_out = sinf(angle);
         return;
@@ -228,8 +233,9 @@ void orc_sincos2pi(float u, float* c_out, float* s_out)
  * z uniform in (-1,1], azimuth uniform. */
 void orc_unit_vector(float u1, float u2, float out[3])
 {
-    float z = lfma(-2.0f, u1, 1.0f);
-    float r = sqrtf(lfma(-z, z, 1.0f));
+    const int fused = !t_lit || t_poly;                    /* the sampler's own recipe */
+    float z = fused ? fmaf(-2.0f, u1, 1.0f) : -2.0f * u1 + 1.0f;
+    float r = sqrtf(fused ? fmaf(-z, z, 1.0f) : -z * z + 1.0f);
     float c, s;
     orc_sincos2pi(u2, &c, &s);
     out[0] = r * c; out[1] = r * s; out[2] = z;
@@ -812,10 +818,10 @@ void orc_camera_ray(const float camera[21], const orc_params* p, uint32_t gx, ui
     pathrng key;
     orc_params q = *p;
     if (q.sample_mode != ORC_SAMPLE_JITTER && q.grid_n == 0) q.grid_n = isqrt_u32(q.first_sample + q.spp);
-    const int lit_before = t_lit;
-    t_lit = q.arith == ORC_ARITH_LITERAL;
+    const int lit_before = t_lit, poly_before = t_poly;
+    set_arith(q.arith);
     ray r = camera_ray(camera, &q, seed_key(p->seed), gx, gy, sample, &key);
-    t_lit = lit_before;
+    t_lit = lit_before; t_poly = poly_before;
     origin[0] = r.o.x; origin[1] = r.o.y; origin[2] = r.o.z;
     dir[0] = r.d.x; dir[1] = r.d.y; dir[2] = r.d.z;
 }
@@ -883,8 +889,8 @@ int orc_render(const orc_shape* shapes, uint32_t n_shapes, const orc_triangle* t
         tracer T; memset(&T, 0, sizeof T);
         T.shapes = shapes; T.n_shapes = n_shapes; T.tris = tris; T.n_tris = n_tris;
         T.cam = camera; T.p = &q; T.seed_k = seed_key(q.seed);
-        const int lit_before = t_lit;                                  /* the flag is per thread: set it in every worker */
-        t_lit = q.arith == ORC_ARITH_LITERAL;
+        const int lit_before = t_lit, poly_before = t_poly;            /* the flags are per thread: set them in every worker */
+        set_arith(q.arith);
 #pragma omp for schedule(dynamic, 1)
         for (int64_t y = 0; y < (int64_t)q.height; ++y) {
             if (!row_in_shard(&q, (uint32_t)y)) continue;
@@ -907,7 +913,7 @@ int orc_render(const orc_shape* shapes, uint32_t n_shapes, const orc_triangle* t
                 }
             }
         }
-        t_lit = lit_before;
+        t_lit = lit_before; t_poly = poly_before;
 #pragma omp critical
         stats_add(&total, &T.st);
     }
@@ -924,8 +930,8 @@ int orc_trace(const orc_shape* shapes, uint32_t n_shapes, const orc_triangle* tr
     tracer T; memset(&T, 0, sizeof T);
     T.shapes = shapes; T.n_shapes = n_shapes; T.tris = tris; T.n_tris = n_tris;
     T.cam = camera; T.p = &q; T.seed_k = seed_key(q.seed);
-    const int lit_before = t_lit;
-    t_lit = q.arith == ORC_ARITH_LITERAL;
+    const int lit_before = t_lit, poly_before = t_poly;
+    set_arith(q.arith);
     for (uint32_t y = 0; y < q.height; ++y)
         for (uint32_t x = 0; x < q.width; ++x) {
             size_t base = ((size_t)y * q.width + x) * q.max_depth;
@@ -933,7 +939,7 @@ int orc_trace(const orc_shape* shapes, uint32_t n_shapes, const orc_triangle* tr
             T.trace_hit = hit_index + base; T.trace_mat = material_id + base;
             (void)path_color(&T, x, y, sample);
         }
-    t_lit = lit_before;
+    t_lit = lit_before; t_poly = poly_before;
     return 0;
 }
 

@@ -52,8 +52,12 @@ enum { ORC_UNIT_DIRECT = 0, ORC_UNIT_GAUSS = 1 };
  * RECIPE  = the fixed recipes the HIP kernels repeat bit for bit (explicit FMAs, Newton reciprocal and reciprocal
  *           root, polynomial sin/cos);
  * LITERAL = the source text as a compiler without contraction evaluates it: no FMA, IEEE divide, v / sqrt(v.v),
- *           libm sinf/cosf, Sphere::hit's distance in double.  Used only to state how far RECIPE is from the text. */
-enum { ORC_ARITH_RECIPE = 0, ORC_ARITH_LITERAL = 1 };
+ *           libm sinf/cosf, Sphere::hit's distance in double.  Used only to state how far RECIPE is from the text.
+ * LITERAL_GEOMETRY = LITERAL for the geometry (intersections, normals, normalisations, reflections, hit distances in
+ *           double), RECIPE for the samplers (polynomial sin/cos, the fused sphere point): what the HIP kernels compute
+ *           under RT_FLAG_LITERAL_GEOMETRY, bit for bit.  Its hit indices equal LITERAL's up to the first scatter
+ *           (first hits: always), since only the sampled directions differ. */
+enum { ORC_ARITH_RECIPE = 0, ORC_ARITH_LITERAL = 1, ORC_ARITH_LITERAL_GEOMETRY = 2 };
 
 typedef struct {
     uint32_t width, height;
@@ -67,7 +71,7 @@ typedef struct {
     int32_t  threads;                               /* <=0: all cores                  */
     uint32_t rng;                                   /* ORC_RNG_HASH / ORC_RNG_GLSL     */
     const float* triangle_colors;                   /* NULL, or rgb per triangle (replaces triangle_albedo) */
-    uint32_t arith;                                 /* ORC_ARITH_RECIPE / ORC_ARITH_LITERAL */
+    uint32_t arith;                                 /* ORC_ARITH_RECIPE / ORC_ARITH_LITERAL / ORC_ARITH_LITERAL_GEOMETRY */
 } orc_params;
 
 typedef struct {

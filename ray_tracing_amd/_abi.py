@@ -20,6 +20,7 @@ RNG_HASH, RNG_GLSL = 0, 1
 FLAG_METAL_UNNORMALIZED = 1
 FLAG_BOX_SIDES = 2
 FLAG_UNIT_GAUSS = 4
+FLAG_LITERAL_GEOMETRY = 8
 MAT_LIGHT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DEBUG = 0, 1, 2, 3, 100
 SHAPE_CIRCLE, SHAPE_BOX, SHAPE_CUBE = 0, 1, 3
 

@@ -355,6 +355,8 @@ static int plan_blob(rt_ctx* ctx, BlobPlan& B)
     // The place of each uploaded triangle in the sorted list is looked up once per hit: it stays in global memory.
     L.inv_off = staged_words;
     L.total_words = L.inv_off + (n_tris + 3u) / 4u;
+    if ((ctx->cfg.flags & RT_FLAG_LITERAL_GEOMETRY) && (n_box != 0 || n_tris != 0))
+        return fail(ctx, RT_ERR_INVALID_ARG, "scene: RT_FLAG_LITERAL_GEOMETRY renders spheres and Cubes only (%u boxes, %u triangles uploaded)", n_box, n_tris);
     B.colors = !ctx->tri_colors.empty() && ctx->tri_colors.size() == 3u * (size_t)n_tris;
     const uint32_t wave_words = (n_tris || n_box) ? rtd::lds_wave_words(ctx->group_waves, false) : 0u;     // queues and slots of the spread tests
     if ((size_t)(L.node_off[rtd::TREE_LEVELS - 1u] + (n_tris ? rtd::lds_wave_words(ctx->group_waves, true) : wave_words)) * 16u > ctx->lds_limit)
@@ -511,6 +513,8 @@ int rt_create(rt_ctx** out, const rt_config* cfg)
     if (c.rng > RT_RNG_GLSL) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown rng %u", c.rng);
     if ((c.flags & RT_FLAG_UNIT_GAUSS) && (c.semantics != RT_SEM_CPU || c.rng != RT_RNG_HASH))
         return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: RT_FLAG_UNIT_GAUSS needs RT_SEM_CPU and RT_RNG_HASH");
+    if ((c.flags & RT_FLAG_LITERAL_GEOMETRY) && (c.semantics != RT_SEM_CPU || c.rng != RT_RNG_HASH || (c.flags & RT_FLAG_UNIT_GAUSS)))
+        return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: RT_FLAG_LITERAL_GEOMETRY needs RT_SEM_CPU and RT_RNG_HASH, without RT_FLAG_UNIT_GAUSS");
     if (c.sample_mode > RT_SAMPLE_GRID_COMPAT) return fail(nullptr, RT_ERR_INVALID_ARG, "rt_create: unknown sample_mode %u", c.sample_mode);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);

@@ -179,6 +179,17 @@ RT_DEV V3 cross(V3 a, V3 b)
 {
     return v3(fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x)));
 }
+// The reference's expressions as a C++ compiler without contraction evaluates them (RT_FLAG_LITERAL_GEOMETRY): every
+// product and sum rounded on its own, v / sqrt(v.v) with the IEEE root and quotient for normalized().
+RT_DEV float dot_plain(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+RT_DEV V3 madd_plain(float t, V3 d, V3 o) { return v3(t * d.x + o.x, t * d.y + o.y, t * d.z + o.z); }
+RT_DEV V3 normalize_plain(V3 v)
+{
+    const float len = __builtin_sqrtf(dot_plain(v, v));
+    return v3(v.x / len, v.y / len, v.z / len);
+}
+template <bool LIT> RT_DEV float dot_as(V3 a, V3 b) { return LIT ? dot_plain(a, b) : dot(a, b); }
+template <bool LIT> RT_DEV V3 madd_as(float t, V3 d, V3 o) { return LIT ? madd_plain(t, d, o) : madd(t, d, o); }
 // GLSL sign(): -1, 0, 1; NaN gives 0.
 RT_DEV float sign_(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 // GLSL max(): (x < y) ? y : x — not v_max_f32, whose NaN rule differs.
@@ -556,7 +567,8 @@ RT_DEV uint32_t quantise(float c)
 // triangles staged in LDS, 2 triangles and their tree read from the blob in global memory; bit 2: the scene holds cubes of the CPU tracer, dielectric
 // materials or a colour per triangle, or the context asks for the reference's normalised-Gaussian sphere sampler (kept out of the other instances, whose registers and issue slots they
 // would cost: 12 % on the four-sphere scene); bit 3: draws come from the
-// shader's own random() instead of the counter hash.  MODE 0: render.  MODE 1: render and count work.  MODE 2:
+// shader's own random() instead of the counter hash; bit 4 (CPU rules, spheres and cubes only): the geometry in the
+// reference's literal arithmetic, see LIT below.  MODE 0: render.  MODE 1: render and count work.  MODE 2:
 // follow one sample, record hit and material ids, leave the accumulator alone.
 //
 // One loop iteration = one ray segment of every live lane: closest hit, then
@@ -584,6 +596,13 @@ void trace_kernel(const TraceParams P,
     // The 64 x (samples) paths of a wave's 8x8 tile are one pool that its lanes draw from (shader rules, whose integer
     // sums take any order): see "pool" below.
     constexpr bool POOL = RT_POOL != 0 && SEM == 1 && !TRACE && (GEO & 3) != 0;
+    // RT_FLAG_LITERAL_GEOMETRY: Sphere::hit, normalAt, the Ray constructor and reflect as scene.h:14-16,115-132 and
+    // utils.h:62-64 are written — no fused operation, normalized() as v / sqrt(v.v) with the IEEE root and quotient,
+    // the hit distance in double (HitRecord::t, scene.h:34; the unqualified sqrt of scene.h:123 is the double one) and
+    // compared as a double (scene.h:237), narrowed where Ray::at multiplies a float vector by it.  The samplers keep
+    // their polynomial (the CPU tracer's stream cannot be reproduced anyway).
+    constexpr bool LIT = (GEO & 16) != 0;
+    static_assert(!LIT || (SEM == 0 && (GEO & 3) == 0 && (GEO & 8) == 0), "literal geometry: CPU rules, spheres and cubes, counter hash");
     constexpr bool HAS_QUEUES = (GEO & 3) != 0, TRI_GLOBAL = (GEO & 3) == 2, SPREAD_BOXES = HAS_QUEUES, HAS_CUBE = SEM == 0 && (GEO & 4) != 0, HAS_GLASS = (GEO & 4) != 0, HAS_TCOL = (GEO & 4) != 0, RNG_GLSL = (GEO & 8) != 0,
                    HAS_GAUSS = SEM == 0 && (GEO & 4) != 0 && (GEO & 8) == 0;
     extern __shared__ float4 lds[];
@@ -634,7 +653,7 @@ void trace_kernel(const TraceParams P,
     const V3 cam_up = v3(P.cam[12], P.cam[13], P.cam[14]);
     const V3 cam_right = v3(P.cam[16], P.cam[17], P.cam[18]);
     // rayTracer.h:77 / glsl:293: upperLeft + step*gx*right - step*gy*up
-    const V3 pc = madd(-(step * (float)gy), cam_up, madd(step * (float)gx, cam_right, v3(P.cam[8], P.cam[9], P.cam[10])));
+    const V3 pc = madd_as<LIT>(-(step * (float)gy), cam_up, madd_as<LIT>(step * (float)gx, cam_right, v3(P.cam[8], P.cam[9], P.cam[10])));
     const uint32_t h1 = hash32(P.seed_key ^ pixel);
 
     // Running sums of this pixel: float for SEM 0, uint for SEM 1.
@@ -663,7 +682,7 @@ void trace_kernel(const TraceParams P,
     auto camera_origin = [&](uint32_t smp, float a1, float a2) -> V3 {       // raw draws
         if (P.sample_mode == 0u) {
             float s1 = kstep * a1, s2 = kstep * a2;                          // step * u, RayTracing.glsl:296
-            return madd(-s2, up_v, madd(s1, right_v, pcur));
+            return madd_as<LIT>(-s2, up_v, madd_as<LIT>(s1, right_v, pcur));
         }
         const uint32_t N = P.grid_n;
         const uint32_t i = (smp / N) % N, j = smp % N;
@@ -707,7 +726,7 @@ void trace_kernel(const TraceParams P,
         float j1, j2;
         start_draws(sample, key, gs, j1, j2);
         o = camera_origin(sample, j1, j2);
-        d = normalize(o - cam_pos);
+        d = LIT ? normalize_plain(o - cam_pos) : normalize(o - cam_pos);
         if (STATS) ++n_samples;
     }
 
@@ -774,7 +793,37 @@ void trace_kernel(const TraceParams P,
         // anything from `far` on loses (t < FLT_MAX, scene.h:237; distance < 1000, glsl:212).
         // The spheres' scan compares keys only and starts one key further out: `far` itself still loses.
         Best best = { Window<SEM>::far - Window<SEM>::tmin, NONE };
-        for (uint32_t c = 0; c < n_chunks; ++c) {
+        float lit_t = 0.0f;                                           // LIT: the closest hit's distance, narrowed (Ray::at)
+        if (LIT) {
+            // Scene::hit, scene.h:232-255, with Sphere::hit as written (scene.h:115-128): distances are doubles and are
+            // compared as doubles; the window is 0.001 < t < FLT_MAX with both limits widened (rayTracer.h:117).  The
+            // first shape of equal distances stays (strict <): the minimum of (t, index).
+            double best_t = __builtin_inf();
+            auto consider = [&](double t, uint32_t id) {
+                const bool take = 0.001 < t && t < (double)__builtin_bit_cast(float, Window<0>::far) && (t < best_t || (t == best_t && id < best.id));
+                best_t = take ? t : best_t;
+                best.id = take ? id : best.id;
+            };
+            for (uint32_t i = 0; i < n_sph; ++i) {
+                const float4 sp = sph[i];
+                const V3 oc = v3(o.x - sp.x, o.y - sp.y, o.z - sp.z);                     // :116
+                const float b = dot_plain(oc, d);                                         // :117
+                const float c = dot_plain(oc, oc) - sp.w;                                 // :118 (radius * radius formed at upload)
+                const float disc = b * b - c;                                             // :119
+                if (!__any(disc >= 0.0f)) continue;                                       // :120
+                const double t = -(double)b - __builtin_sqrt((double)disc);               // :123
+                consider(disc >= 0.0f ? t : __builtin_inf(), reinterpret_cast<const uint32_t*>(sid)[i]);
+            }
+            if (HAS_CUBE) {
+                for (uint32_t i = 0; i < L.n_cube; ++i) {
+                    V3 ip;
+                    const float t = hit_cube(cub[4u * i], cub[4u * i + 1u], cub[4u * i + 2u], o, d, ip);
+                    consider((double)t, __float_as_uint(cub[4u * i + 3u].x));
+                }
+            }
+            lit_t = best.id == NONE ? 0.0f : (float)best_t;
+        }
+        for (uint32_t c = 0; !LIT && c < n_chunks; ++c) {
             const float4 s0 = sph[4u * c], s1 = sph[4u * c + 1u], s2 = sph[4u * c + 2u], s3 = sph[4u * c + 3u];
             const float4 ids = sid[c];
             test_sphere<SEM>(s0, __float_as_uint(ids.x), o, d, best);
@@ -783,9 +832,9 @@ void trace_kernel(const TraceParams P,
             test_sphere<SEM>(s3, __float_as_uint(ids.w), o, d, best);
         }
         // the one to three spheres behind the last whole chunk, one at a time: the padding of their chunk is not tested
-        for (uint32_t i = 4u * n_chunks; i < n_sph; ++i)
+        for (uint32_t i = 4u * n_chunks; !LIT && i < n_sph; ++i)
             test_sphere<SEM>(sph[i], reinterpret_cast<const uint32_t*>(sid)[i], o, d, best);
-        if (HAS_QUEUES || HAS_CUBE) best.key = (best.id == NONE) ? Window<SEM>::far - 1u - Window<SEM>::tmin : best.key;
+        if (!LIT && (HAS_QUEUES || HAS_CUBE)) best.key = (best.id == NONE) ? Window<SEM>::far - 1u - Window<SEM>::tmin : best.key;
         RT_PHASE_MARK(0)
         // The lanes still tracing, and this lane's place among them: they share the queued tests.
         uint32_t n_live = 64u, lane_rank = lane;
@@ -859,7 +908,7 @@ void trace_kernel(const TraceParams P,
             }
             if (STATS) n_box_test += n_box;
         }
-        if (HAS_CUBE) {
+        if (!LIT && HAS_CUBE) {
             for (uint32_t i = 0; i < L.n_cube; ++i) {
                 V3 ip;
                 const float t = hit_cube(cub[4u * i], cub[4u * i + 1u], cub[4u * i + 2u], o, d, ip);
@@ -1031,8 +1080,8 @@ void trace_kernel(const TraceParams P,
         // (whose colour is stored as 1: glsl:253,282-284 returns the throughput), 0 otherwise — so that the colour
         // a path returns is a product, not a chain of cases.  A miss reads the record behind the shapes' (class 0,
         // emit 0).  Colours are taken to be finite (0 x colour = 0).
-        const float t_hit = __uint_as_float(best_key + Window<SEM>::tmin);
-        const V3 p = madd(t_hit, d, o);                               // Ray::at / glsl:239
+        const float t_hit = LIT ? lit_t : __uint_as_float(best_key + Window<SEM>::tmin);
+        const V3 p = madd_as<LIT>(t_hit, d, o);                       // Ray::at / glsl:239
         const bool is_tri = HAS_QUEUES && (best_id - n_shapes) < L.n_tris;       // a miss (NONE) wraps far beyond
         const uint32_t rid = min(best_id, n_shapes);
         const float4 r0 = rec[4u * rid], r1 = rec[4u * rid + 1u];
@@ -1047,11 +1096,14 @@ void trace_kernel(const TraceParams P,
         // be hit is a sphere.
         if ((!HAS_QUEUES && !HAS_CUBE) || stype == 0u) {
             const V3 pc_ = v3(p.x - r0.x, p.y - r0.y, p.z - r0.z);
+            if (LIT) n = normalize_plain(pc_);                        // scene.h:130-132 as written
+            else {
             n = sphere_normal(pc_, r2.z);                             // scene.h:130-132
             // A fuzzy metal's direction left as written is not unit, and the sphere test, which assumes it is, then
             // returns a point off the sphere: the radius is no first guess of that length.  (A branch on the launch's
             // flags; the empty statement keeps it one.)
             if (SEM == 0 && !cull) { asm volatile(""); n = normalize(pc_); }
+            }
         }
         else if (HAS_QUEUES && stype == 1u) { const float4 r3 = rec[4u * rid + 3u]; n = box_normal(xyz(r0), r2.z, r3.z, r3.w, p); }
         else if (HAS_CUBE && stype == 3u) {
@@ -1180,7 +1232,7 @@ void trace_kernel(const TraceParams P,
             thr = ta;                                                 // scene.h:56 (0.6*albedo, formed at upload), :79; glsl:241,246,275
             if (diffuse) {
                 if (SEM == 0) {
-                    v = madd(1.0001f, n, sphere_point(u1, u2));       // Lambertian::scatter, scene.h:51-58; utils.h:48-50
+                    v = madd_as<LIT>(1.0001f, n, sphere_point(u1, u2));   // Lambertian::scatter, scene.h:51-58; utils.h:48-50
                 } else {
                     v = hemisphere_glsl(n, u1, u2);                   // glsl:240,274
                     raw_dir = true;
@@ -1189,21 +1241,22 @@ void trace_kernel(const TraceParams P,
                 // Dielectric (no counterpart in the reference): at the surface the ray is mirrored with
                 // Schlick's probability and refracted otherwise; the sphere test knows only the near
                 // root, so a refracted ray leaves the sphere without a second event.
-                const float cosi = -dot(d, n);
+                const float cosi = -dot_as<LIT>(d, n);
                 const float x = 1.0f - cosi, x2 = x * x;
                 const float refl = fma_(1.0f - glass_r0, (x2 * x2) * x, glass_r0);
-                const V3 perp = madd(cosi, n, d) * glass_eta;
-                const float par = -sqrt_rn(__builtin_fabsf(1.0f - dot(perp, perp)));
-                const V3 refr = madd(par, n, perp);
-                const V3 mirr = madd(-(2.0f * dot(d, n)), n, d);
+                const V3 perp = madd_as<LIT>(cosi, n, d) * glass_eta;
+                const float one_less = 1.0f - dot_as<LIT>(perp, perp);
+                const float par = -(LIT ? __builtin_sqrtf(__builtin_fabsf(one_less)) : sqrt_rn(__builtin_fabsf(one_less)));
+                const V3 refr = madd_as<LIT>(par, n, perp);
+                const V3 mirr = madd_as<LIT>(-(2.0f * dot_as<LIT>(d, n)), n, d);
                 const bool mirror = u1 * RAW < refl;
                 v = v3(mirror ? mirr.x : refr.x, mirror ? mirr.y : refr.y, mirror ? mirr.z : refr.z);
             } else if (SEM == 0) {
                 // Metal::scatter, scene.h:73-81; reflect, utils.h:62-64
-                v = madd(-(2.0f * dot(n, d)), n, d);
-                if (fuzz != 0.0f) v = madd(fuzz, sphere_point(u1, u2), v);
+                v = madd_as<LIT>(-(2.0f * dot_as<LIT>(n, d)), n, d);
+                if (fuzz != 0.0f) v = madd_as<LIT>(fuzz, sphere_point(u1, u2), v);
                 raw_dir = (P.flags & 1u) != 0u;
-                if (!(dot(v, n) > 0.0f)) {
+                if (!(dot_as<LIT>(v, n) > 0.0f)) {
                     // absorbed: emit() = 0 (scene.h:80,83-85).  The path ends here after all;
                     // this rare case starts the next sample with draws of its own.
                     if (STATS) ++n_terminal;
@@ -1230,8 +1283,13 @@ void trace_kernel(const TraceParams P,
         }
         RT_PHASE_MARK2(2)
         // normalize(v), or v as it is: one select on the factor instead of three on the components (v * 1 = v)
-        const float inv_len = raw_dir ? 1.0f : rsqrt_nr(dot(v, v));
-        d = v * inv_len;
+        if (LIT) {
+            const V3 unit = normalize_plain(v);                       // the Ray constructor, scene.h:14-16
+            d = v3(raw_dir ? v.x : unit.x, raw_dir ? v.y : unit.y, raw_dir ? v.z : unit.z);
+        } else {
+            const float inv_len = raw_dir ? 1.0f : rsqrt_nr(dot(v, v));
+            d = v * inv_len;
+        }
         RT_PHASE_MARK(3)
         RT_PHASE_MARK2(3)
     }
@@ -1494,12 +1552,13 @@ hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams
     const dim3 grid((4u * n_workgroups + P.group_waves - 1u) / P.group_waves);
     const size_t lds_bytes = ((size_t)P.scene.lds_words + (tri_mode ? lds_wave_words(P.group_waves, tri_mode == 2) : 0u)) * 16u;
     const int geo = tri_mode | (((sem == 0 && P.scene.n_cube != 0) || P.scene.has_glass || P.scene.tcol_off != 0 || (P.flags & 4u) != 0u) ? 4 : 0) |
-                    (P.rng_mode ? 8 : 0);
+                    (P.rng_mode ? 8 : 0) | ((P.flags & RT_FLAG_LITERAL_GEOMETRY) != 0u ? 16 : 0);
 #define RT_CASE(S, G, M) if (sem == S && geo == G && mode == M) return launch_one<S, G, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm, tile_order, tile_cost)
 #define RT_CASES(S, G) RT_CASE(S, G, 0); RT_CASE(S, G, 1); RT_CASE(S, G, 2)
 #define RT_GEOS(S) RT_CASES(S, 0); RT_CASES(S, 1); RT_CASES(S, 2); RT_CASES(S, 4); RT_CASES(S, 5); RT_CASES(S, 6); \
                    RT_CASES(S, 8); RT_CASES(S, 9); RT_CASES(S, 10); RT_CASES(S, 12); RT_CASES(S, 13); RT_CASES(S, 14)
     RT_GEOS(0); RT_GEOS(1);
+    RT_CASES(0, 16); RT_CASES(0, 20);                      // literal geometry: CPU rules, spheres and cubes, counter hash
 #undef RT_GEOS
 #undef RT_CASES
 #undef RT_CASE

@@ -235,7 +235,23 @@ def config_box_sides(width=320, height=200, spp=16, max_depth=6, semantics=SEM_G
                        width, height, spp, max_depth, semantics, flags=_abi.FLAG_BOX_SIDES)
 
 
-CONFIGS = {"colored_mesh": config_colored_mesh, "box_sides": config_box_sides, "cpu_tracer": config_cpu_tracer, "c1": config1, "c2": config2, "c3": config3, "c4": config4, "c5": config5, "c5e": config5_enclosed}
+def config_sphere_normals(which="far", radius=None, width=64, height=64):
+    """One sphere with the debug material (shape.h:37-42: the normal is the colour), CPU rules, one sample per pixel
+    on the pixel's corner, seen through a long lens so that it fills the frame.  "far": radius 0.5 at 16 100 from
+    the coordinate origin, where the hit point is off the sphere by up to 1e-3 of the radius (the rounding of its
+    coordinates) and the radius is no first guess of |point - centre|; "near": radius 0.5 at distance 4 (`radius`
+    overrides it: a negative one must give the same frame, Sphere::hit squares it, scene.h:118)."""
+    far = which == "far"
+    r = radius if radius is not None else 0.5
+    dist = 16100.0 if far else 4.0
+    focal = 16000.0 if far else 3.0
+    cam = host.Camera(width, height, focal, (0.0, 0.0, 0.0)).data.copy()
+    shapes = _shapes([host.Circle((0.03, -0.02, -dist), r, host.DebugMaterial((1, 1, 1)))])
+    return SceneConfig("sphere_normals_" + which, shapes, np.zeros(0, TRIANGLE_DTYPE), cam, width, height, 1, 2, SEM_CPU,
+                       sample_mode=_abi.SAMPLE_GRID)
+
+
+CONFIGS = {"sphere_normals": config_sphere_normals, "colored_mesh": config_colored_mesh, "box_sides": config_box_sides, "cpu_tracer": config_cpu_tracer, "c1": config1, "c2": config2, "c3": config3, "c4": config4, "c5": config5, "c5e": config5_enclosed}
 
 
 def make_renderer(cfg, device=0):

@@ -17,6 +17,8 @@ COUNTERS = ("samples", "segments", "diffuse", "specular", "terminal",
 def oracle_params(orc, cfg, **kw):
     args = dict(seed=cfg.seed, semantics=cfg.semantics, sample_mode=cfg.sample_mode, flags=cfg.flags,
                 triangle_albedo=cfg.triangle_albedo, rng=cfg.rng, triangle_colors=cfg.triangle_colors)
+    if cfg.flags & 8:                    # RT_FLAG_LITERAL_GEOMETRY: the oracle's arithmetic of that name
+        args["arith"] = orc.ARITH_LITERAL_GEOMETRY
     args.update(kw)
     return orc.params(cfg.width, cfg.height, cfg.spp, cfg.max_depth, **args)
 
@@ -93,6 +95,62 @@ def test_hip_frame_within_the_literal_bound(rta, orc, name):
     want = json.load(open(os.path.join(here, "golden", "literal_vs_recipe.json")))["configs"][name]
     for k in ("first_hits_differing", "segment_hit_agreement_percent", "image_psnr_db", "image_max_abs"):
         assert r[k] == want[k], (k, r[k], want[k])
+
+
+@pytest.mark.parametrize("which,radius", [("far", None), ("near", None), ("near", -0.5)])
+def test_sphere_normals_far_from_the_origin_and_with_a_negative_radius(rta, orc, which, radius):
+    """The debug material shows the normal: a sphere whose hit points are off it by 1e-3 of the radius (the kernel's
+    one-step normal falls back on the full normalisation there) and a sphere with a negative radius (the stored
+    first guess is 1/|radius|)."""
+    cfg = rta.scenes.config_sphere_normals(which, radius)
+    check_config(rta, orc, cfg, grid_n=1)
+    rt = rta.scenes.make_renderer(cfg)
+    rt.render(cfg.width, cfg.height, 1, cfg.max_depth, cfg.seed, grid_n=1)
+    n = rt.resolve(cfg.width, cfg.height)[..., :3].astype(np.float64)
+    rt.close()
+    length = np.sqrt((n ** 2).sum(-1))
+    assert (length > 0).sum() > 1000 and np.abs(length[length > 0] - 1.0).max() < 4e-7
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c4", "c5", "cpu_tracer"])
+def test_literal_geometry_mode(rta, orc, name):
+    """RT_FLAG_LITERAL_GEOMETRY: Sphere::hit, normalAt, the Ray constructor and reflect as scene.h:14-23,115-132 and
+    utils.h:62-64 are written (no fused operation, v / sqrt(v.v), the hit distance in double).  Bit for bit against
+    the oracle's arithmetic of the same name — counters, image words, followed hit and material ids — and the FIRST
+    hits of every pixel equal those of the fully literal arithmetic (which differs only in its samplers' sine and
+    cosine, i.e. from the first scatter on): 0 differing, where the default recipes differ on silhouettes."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from literal_study import cases
+    cfg, grid_n = cases(rta.scenes)[name]
+    cfg.flags |= rta.FLAG_LITERAL_GEOMETRY
+    check_config(rta, orc, cfg, trace_samples=(0, 1, 2, 3), grid_n=grid_n)
+    rt = rta.scenes.make_renderer(cfg)
+    p_lit = oracle_params(orc, cfg, grid_n=grid_n, arith=orc.ARITH_LITERAL)
+    differing = later = later_same = 0
+    for s in range(4):
+        hit, mat = rt.traceDebug(cfg.width, cfg.height, cfg.max_depth, cfg.seed, s, grid_n=grid_n)
+        lhit, lmat = orc.trace(cfg.shapes, cfg.triangles, cfg.camera, p_lit, s)
+        differing += int((hit[..., 0] != lhit[..., 0]).sum()) + int((mat[..., 0] != lmat[..., 0]).sum())
+        live = (hit != -2) | (lhit != -2)
+        later += int(live.sum()); later_same += int(((hit == lhit) & live).sum())
+    rt.close()
+    assert differing == 0
+    assert later_same >= 0.995 * later          # later segments: only the samplers' last bits separate the two
+
+
+def test_literal_geometry_flag_is_refused_where_it_does_not_apply(rta):
+    cfg = rta.scenes.config3(width=32, height=32, spp=1, max_depth=2)
+    cfg.semantics = 0
+    cfg.flags |= rta.FLAG_LITERAL_GEOMETRY
+    with pytest.raises(rta.RtError):
+        rta.scenes.make_renderer(cfg)           # boxes and triangles
+    cfg = rta.scenes.config1(width=32, height=32)
+    cfg.flags |= rta.FLAG_LITERAL_GEOMETRY
+    cfg.semantics = 1
+    with pytest.raises(rta.RtError):
+        rta.scenes.make_renderer(cfg)           # the shader's rules
 
 
 def test_config1_cpu_sphere_scene(rta, orc):

@@ -75,3 +75,23 @@ def test_leaf_routines_in_both_arithmetics(orc):
     assert worst_sc <= 1.5e-6          # polynomial sin/cos against libm's, absolute
     assert worst_box <= 2e-6           # Newton reciprocal against the IEEE divide, relative, through hitBox
     assert flips <= 2                  # of 2000 random rays
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c4", "c5", "cpu_tracer"])
+def test_literal_geometry_arithmetic_has_the_literal_first_hits(rta, orc, name):
+    """ORC_ARITH_LITERAL_GEOMETRY (what the HIP kernels compute under RT_FLAG_LITERAL_GEOMETRY) evaluates the geometry
+    as the fully literal arithmetic does and keeps only the samplers' polynomial: every first hit is the same, later
+    segments differ only where a sampled direction's last bits decide a hit."""
+    cfg, grid_n = cases(rta.scenes)[name]
+    from literal_study import oracle_params
+    pg = oracle_params(orc, cfg, grid_n=grid_n, arith=orc.ARITH_LITERAL_GEOMETRY)
+    pl = oracle_params(orc, cfg, grid_n=grid_n, arith=orc.ARITH_LITERAL)
+    n = same = 0
+    for s in range(min(4, cfg.spp)):
+        hg, mg = orc.trace(cfg.shapes, cfg.triangles, cfg.camera, pg, s)
+        hl, ml = orc.trace(cfg.shapes, cfg.triangles, cfg.camera, pl, s)
+        np_equal = (hg[..., 0] == hl[..., 0]).all() and (mg[..., 0] == ml[..., 0]).all()
+        assert np_equal, f"{name}, sample {s}: first hits differ"
+        live = (hg != -2) | (hl != -2)
+        n += int(live.sum()); same += int(((hg == hl) & live).sum())
+    assert same >= 0.995 * n

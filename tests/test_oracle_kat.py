@@ -460,3 +460,25 @@ def test_tangent_fallback_threshold(orc):
         v = orc.hemisphere_glsl(tuple(float(x) for x in n), 0.0, 0.0)        # angle 0, r 0: the first tangent itself
         want = np.array([0.0, -n[2], n[1]]) / math.hypot(n[2], n[1]) if fallback else np.array([-n[1], n[0], 0.0]) / math.hypot(n[0], n[1])
         np.testing.assert_allclose(np.asarray(v, dtype=np.float64), want, atol=2e-6)
+
+
+def test_sphere_normals_are_unit_and_ignore_the_radius_sign(rta, orc):
+    """normalAt (scene.h:130-132) is (point - centre).normalized(): unit length wherever the sphere is, and the same
+    for a radius of either sign (Sphere::hit squares it, scene.h:118).  The recipe's one Newton step from 1/|radius|
+    must fall back on the full normalisation where the hit point is off the sphere by more than it can absorb."""
+    frames = {}
+    for which, radius in (("far", None), ("near", None), ("near", -0.5)):
+        cfg = rta.scenes.config_sphere_normals(which, radius)
+        for arith in (orc.ARITH_RECIPE, orc.ARITH_LITERAL):
+            p = orc.params(cfg.width, cfg.height, 1, cfg.max_depth, seed=1, semantics=cfg.semantics, sample_mode=cfg.sample_mode,
+                           grid_n=1, arith=arith)
+            acc, _ = orc.render(cfg.shapes, cfg.triangles, cfg.camera, p)
+            n = acc.view(np.float32)[..., :3].astype(np.float64)          # debug material, one sample: the sum is the normal
+            length = np.sqrt((n ** 2).sum(-1))
+            hit = length > 0
+            assert hit.sum() > 1000
+            assert np.abs(length[hit] - 1.0).max() < 4e-7, (which, radius, arith)
+            assert n[..., 2][hit].min() >= 0.0 and n[..., 2][hit].mean() > 0.5   # towards the camera: outward
+            frames[(which, radius, arith)] = acc
+    for arith in (orc.ARITH_RECIPE, orc.ARITH_LITERAL):
+        np.testing.assert_array_equal(frames[("near", None, arith)], frames[("near", -0.5, arith)])
