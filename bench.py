@@ -3,8 +3,9 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one full frame of the workload: clear the accumulator, trace `spp` samples per pixel, exchange the
-ranks' accumulators (RCCL) when N > 1, resolve on rank 0.  Consecutive frames use two accumulators in turn: on one
+A step is one full frame of the workload: the accumulator starts from zero (rt_discard_accum: the launch overwrites it,
+nothing is cleared), `spp` samples per pixel are traced, the ranks' accumulators are exchanged (RCCL) when N > 1, and the
+frame is resolved on rank 0 (on one GPU by the launch itself, rt_render_resolved).  Consecutive frames use two accumulators in turn: on one
 GPU each has its own stream, so that one launch's ramp and tail are filled by the next frame's; with N > 1 one
 frame's exchange runs beside the next frame's trace.  The launch duration quoted under "roofline" is measured
 separately with one frame in flight.  The scene and camera are resident in HBM
@@ -42,7 +43,8 @@ def algorithmic_flops(st, executed=True):
     their bounds); executed=False prices the reference's exhaustive scan of every triangle and box."""
     tri = st["triangle_tests_done"] * F_TRI + st["bound_tests_done"] * F_BOUND if executed else st["triangle_tests"] * F_TRI
     box = st["box_tests_done"] * F_BOX + st["box_bound_tests_done"] * F_BOX_BOUND if executed else st["box_tests"] * F_BOX
-    return (st["samples"] * F_CAMERA + st["sphere_tests"] * F_SPHERE + box + tri +
+    sph = st["sphere_tests_done"] if executed else st["sphere_tests"]      # camera rays test only the spheres their tile can see
+    return (st["samples"] * F_CAMERA + sph * F_SPHERE + box + tri +
             st["diffuse"] * F_DIFFUSE + st["specular"] * F_SPECULAR + st["terminal"] * F_TERMINAL)
 
 
@@ -271,12 +273,19 @@ def main():
             outs.append(torch.empty(cfg.height, cfg.width, 4, dtype=torch.float32, device="cuda"))
         torch.cuda.synchronize()
 
+        gamma = cfg.semantics == rta.SEM_CPU
+
         def trace(k, ev=None):
             rt = rts[k % n_buf]
-            rt.resetAccum()                       # hipMemsetAsync of the bound accumulator on the context's stream
+            rt.discardAccum()                     # the frame starts from zero: the launch overwrites the accumulator, nothing is cleared
             if ev:
                 ev[0].record(streams[k % n_buf])
-            rt.render(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, first_sample=shard.first_sample)
+            if world == 1:
+                # one GPU: the frame's resolve rides on the launch that ends it (rt_render_resolved)
+                rt.renderResolved(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, outs[k % n_buf].data_ptr(),
+                                  first_sample=shard.first_sample, gamma_sqrt=gamma, flip_rows=True)
+            else:
+                rt.render(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, first_sample=shard.first_sample)
             if ev:
                 ev[1].record(streams[k % n_buf])
             return k, parallel.exchange_framebuffer(accums[k % n_buf], cfg.semantics, shard, async_op=True)
@@ -285,10 +294,10 @@ def main():
             k, work = pending
             if work is not None:
                 work.wait()                       # the current stream waits for the collective
-            if rank == 0:
+            if rank == 0 and world > 1:
                 rt = rts[k % n_buf]
                 rt.setAccumSamples(parallel.total_samples(shard))
-                rt.resolveDevice(outs[k % n_buf].data_ptr(), gamma_sqrt=(cfg.semantics == rta.SEM_CPU), flip_rows=True)
+                rt.resolveDevice(outs[k % n_buf].data_ptr(), gamma_sqrt=gamma, flip_rows=True)
 
         def run(n, events=None, one_context=False):
             pending = None
@@ -328,6 +337,22 @@ def main():
         # ... 1.03 from the twentieth on); K timed steps of a millisecond each would measure that ramp, not the
         # renderer.  So the same frames run untimed for --settle-ms first (at most 2 000 of them) — every rank the same number, the count
         # derived from the slowest rank's time for the first few — and the line says how many ("clock_settle_frames").
+        # The same K steps once before that, as a run that does not wait for the clocks measures them ("value_unsettled").
+        unsettled_ms = None
+        if not args.counters_child and args.settle_ms > 0:
+            run(args.warmup)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            tu = time.perf_counter()
+            run(args.steps)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            tu = torch.tensor([time.perf_counter() - tu], dtype=torch.float64, device="cuda")
+            if world > 1:
+                dist.all_reduce(tu, op=dist.ReduceOp.MAX)
+            unsettled_ms = float(tu.item()) / args.steps * 1e3
         settle_frames = 0
         if not args.counters_child and args.settle_ms > 0:
             torch.cuda.synchronize()
@@ -360,6 +385,33 @@ def main():
         run(args.steps, events, one_context=(world == 1))
         torch.cuda.synchronize()
         kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
+        # What a frame costs the host to queue, and how long the exchange takes: the same frames once more, one at a
+        # time with the device idle before each (nothing overlaps, so the parts can be told apart).  exchange_ms runs
+        # from the end of this rank's trace to the end of the collective on this rank: it includes waiting for the
+        # slowest rank's trace.
+        host_ms, exchange_ms = [], []
+        for k in range(min(args.steps, 8)):
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            th = time.perf_counter()
+            rt = rts[k % n_buf]
+            rt.discardAccum()
+            if world == 1:
+                rt.renderResolved(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, outs[k % n_buf].data_ptr(),
+                                  first_sample=shard.first_sample, gamma_sqrt=gamma, flip_rows=True)
+            else:
+                rt.render(cfg.width, cfg.height, shard.spp, cfg.max_depth, cfg.seed, first_sample=shard.first_sample)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(streams[k % n_buf])
+            work = parallel.exchange_framebuffer(accums[k % n_buf], cfg.semantics, shard, async_op=True)
+            finish((k, work))
+            e1.record(streams[k % n_buf])
+            host_ms.append((time.perf_counter() - th) * 1e3)
+            torch.cuda.synchronize()
+            exchange_ms.append(e0.elapsed_time(e1))
+        host_ms_per_frame = sum(host_ms) / len(host_ms)
+        exchange_ms = sum(exchange_ms) / len(exchange_ms) if world > 1 else None
 
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         if world > 1:
@@ -368,7 +420,8 @@ def main():
         if world > 1:
             dist.all_reduce(samples)
         m = {"shard": shard, "stats": stats, "elapsed": float(t.item()), "samples_per_step": int(samples.item()),
-             "kernel_ms": kernel_ms, "cold_ms": cold_ms, "rts": rts, "accums": accums, "settle_frames": settle_frames}
+             "kernel_ms": kernel_ms, "cold_ms": cold_ms, "rts": rts, "accums": accums, "settle_frames": settle_frames,
+             "unsettled_ms": unsettled_ms, "host_ms_per_frame": host_ms_per_frame, "exchange_ms": exchange_ms}
         return m
 
     def release(m):
@@ -384,6 +437,8 @@ def main():
         other = {"shard": other_mode, "scaling": "weak" if other_mode == "samples" else "strong",
                  "value": round(mo["samples_per_step"] / (mo["elapsed"] / args.steps) / 1e6, 2), "unit": "Msamples/s",
                  "ms_per_step": round(mo["elapsed"] / args.steps * 1e3, 4), "kernel_ms": round(mo["kernel_ms"], 4),
+                 "exchange_ms": None if mo["exchange_ms"] is None else round(mo["exchange_ms"], 4),
+                 "host_ms_per_frame": round(mo["host_ms_per_frame"], 4),
                  "exchange_bytes_per_rank": parallel.exchange_bytes(other_mode, cfg.width, cfg.height, world)}
         release(mo)
     m = measure(args.shard)
@@ -447,6 +502,13 @@ def main():
         result = {
             "metric": "Msamples/sec at 1080p", "value": round(value, 2), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            # the same K steps timed before the device's clocks had settled (no --settle-ms): what a short cold run sees
+            "value_unsettled": None if m["unsettled_ms"] is None else round(samples_per_step / (m["unsettled_ms"] * 1e-3) / 1e6, 2),
+            "ms_per_step_unsettled": None if m["unsettled_ms"] is None else round(m["unsettled_ms"], 4),
+            # host time to queue one frame (discard, render, exchange, resolve; the device idle, nothing waited for)
+            "host_ms_per_frame": round(m["host_ms_per_frame"], 4),
+            # N > 1: from the end of this rank's trace to the end of the framebuffer exchange on rank 0 (HIP events)
+            "exchange_ms": None if m["exchange_ms"] is None else round(m["exchange_ms"], 4),
             "higher_is_better": True, "scaling": "weak" if args.shard == "samples" else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg.name}: {cfg.width}x{cfg.height}, {shard.spp} spp per GPU, depth {cfg.max_depth}, "
@@ -460,6 +522,8 @@ def main():
             # share of the lane-iterations of the bounce loop that traced a segment (the rest: lanes whose pixel had
             # no samples left while their wave went on)
             "lane_use": round(stats["segments"] / max(1, 64 * stats["wave_iterations"]), 4),
+            # steps of a wave that traced camera rays only, from their tile's candidate list (instances with boxes or a mesh)
+            "primary_steps_share": round(stats["primary_steps"] / max(1, stats["wave_iterations"]), 4),
             "cold_first_frame_ms": None if cold_ms is None else round(cold_ms, 4),
             # untimed frames run before the warm-up steps so that the device is at its sustained clock (--settle-ms)
             "clock_settle_frames": m["settle_frames"],
@@ -477,7 +541,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             def gpu_render(spp):
                 rt = rts[0]
-                rt.resetAccum()
+                rt.discardAccum()
                 rt.render(cfg.width, cfg.height, spp, cfg.max_depth, cfg.seed)
                 torch.cuda.synchronize()
                 return accums[0].cpu().numpy().view("uint32")

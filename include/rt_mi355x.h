@@ -169,6 +169,8 @@ typedef struct rt_stats {
     uint64_t work_units;           /* workgroups that traced: the tiles, plus one per extra slice of a tile's sample range */
     uint64_t box_tests_done;       /* ray-box tests this library executed (it culls by the boxes' bounds) */
     uint64_t box_bound_tests_done; /* slab tests of those bounds it executed to do so */
+    uint64_t sphere_tests_done;    /* ray-sphere tests this library executed (camera rays test only the spheres their tile can see) */
+    uint64_t primary_steps;        /* of wave_iterations: steps that traced camera rays only, from their tile's candidate list */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;
@@ -250,6 +252,15 @@ int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp,
               uint32_t max_depth, uint64_t seed, uint32_t first_sample,
               uint32_t grid_n);
 
+/* rt_render followed by rt_resolve_device, as one call: the same words in the accumulator and in `rgba_device`
+ * (width*height RGBA float32 on the context's device).  Where every pixel's sum is formed by one lane of one launch —
+ * always under RT_SEM_CPU, and under RT_SEM_GLSL while the launch plan cuts no tile's sample range — the launch that
+ * ends the frame writes the resolved pixel from the sums it holds in registers, and no resolve kernel runs: the
+ * converter dispatch of src/main.cpp:147-149 folded into the compute dispatch of :145.  Asynchronous. */
+int rt_render_resolved(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp,
+                       uint32_t max_depth, uint64_t seed, uint32_t first_sample,
+                       uint32_t grid_n, float* rgba_device, int gamma_sqrt, int flip_rows);
+
 /* rt_render for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid it).  No counterpart in the reference.  It adds the same
  * samples to `accum_device` (caller-owned, width*height*4 32-bit words, 16-byte aligned, on the
@@ -295,6 +306,14 @@ int rt_set_accum_samples(rt_ctx* ctx, uint32_t samples);
 
 /* main.cpp:179,194 (number_of_samples = 1): drop everything accumulated. */
 int rt_reset_accum(rt_ctx* ctx);
+
+/* The same for a caller that renders next: nothing is cleared now; the next render call starts its sums from zero
+ * and stores them instead of reading the accumulator and adding (where its launch plan cuts a tile's sample range,
+ * whose slices meet in the accumulator through atomics, it clears first after all).  The frame that call leaves is
+ * the one rt_reset_accum + that call leave — in the rows the context renders: with a row shard set
+ * (rt_set_row_shard) the other rows keep what they held.  No counterpart in the reference, whose converter clears
+ * the pixel buffer it has just read (PixelConversion.glsl:25-27). */
+int rt_discard_accum(rt_ctx* ctx);
 
 /* ---------------------------------------------------------------- resolve */
 

@@ -43,7 +43,7 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "segments", "diffuse", "specular", "terminal",
                                           "shape_tests", "sphere_tests", "box_tests", "triangle_tests",
                                           "triangle_tests_done", "bound_tests_done", "wave_iterations", "work_units",
-                                          "box_tests_done", "box_bound_tests_done")]
+                                          "box_tests_done", "box_bound_tests_done", "sphere_tests_done", "primary_steps")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -74,6 +74,8 @@ SIGNATURES = {
     "rt_accum_samples": (_int, [_vp, C.POINTER(_u32)]),
     "rt_set_accum_samples": (_int, [_vp, _u32]),
     "rt_reset_accum": (_int, [_vp]),
+    "rt_discard_accum": (_int, [_vp]),
+    "rt_render_resolved": (_int, [_vp, _u32, _u32, _u32, _u32, _u64, _u32, _u32, _vp, _int, _int]),
     "rt_resolve": (_int, [_vp, _vp, _int, _int]),
     "rt_resolve_device": (_int, [_vp, _vp, _int, _int]),
     "rt_convert": (_int, [_vp, _u32]),

@@ -24,7 +24,8 @@
 namespace rtd {
 hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams& P, const void* blob,
                         uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm,
-                        const uint32_t* tile_order, uint32_t* tile_cost, uint32_t n_workgroups);
+                        const uint32_t* tile_order, uint32_t* tile_cost, uint32_t n_workgroups, const uint32_t* tile_lists);
+hipError_t launch_tile_lists(hipStream_t stream, const TraceParams& P, const void* blob, uint32_t* lists);
 hipError_t launch_tile_plan(hipStream_t stream, uint32_t* cost, uint32_t* work, uint32_t n, uint32_t extra, uint32_t max_slices, float share, float early_share);
 hipError_t launch_trace_fill(hipStream_t stream, int32_t* hit, uint32_t* mat, size_t n);
 hipError_t launch_resolve(int sem, hipStream_t stream, const uint32_t* accum, float* out, uint32_t w, uint32_t h,
@@ -77,6 +78,24 @@ struct rt_ctx {
     uint32_t order_tiles_x = 0, order_tiles_y = 0;   // tiling the plan is valid for (0 = none yet)
     uint32_t plan_units = 0;             // workgroups of the planned launch
     uint32_t plan_max_slices = 1;        // the most slices a tile of that plan may have been cut into
+    // What the plan was made from.  While a call renders the same view (scene, camera, samples, depth), the plan is
+    // kept and no costs are collected; every REPLAN_EVERY-th such call renews it.
+    struct PlanView { float cam[RT_CAMERA_FLOATS]; uint32_t scene_version, spp, max_depth, shard_index, shard_count, band_rows; };
+    PlanView plan_view{};
+    uint32_t plan_age = 0;               // calls that reused the plan since it was made
+    bool discard_pending = false;        // rt_discard_accum: the next render call overwrites the accumulator
+
+    // Candidate lists of the camera rays, one record per 8x8-pixel wave tile (rt_device.h): made by the first render
+    // of a (scene, camera, frame size, row shard) and kept until one of them changes.
+    struct ListKey {
+        float cam[RT_CAMERA_FLOATS];
+        uint32_t width, height, sample_mode, grid_n, shard_index, shard_count, band_rows, owned_rows, tiles_x, tiles_y, scene_version;
+    };
+    uint32_t* d_tile_lists = nullptr;
+    uint32_t lists_cap = 0;              // wave tiles allocated for
+    bool lists_valid = false;
+    ListKey lists_key{};
+    uint32_t scene_version = 0;          // counts the builds of the device copy of the scene
 
     int compute_units = 0;
     uint32_t lds_limit = rtd::LDS_WORKGROUP_MAX_BYTES;   // what a workgroup can have of a CU's LDS on this device (hipDeviceProp_t::sharedMemPerBlock, at most 160 KiB)
@@ -87,7 +106,7 @@ struct rt_ctx {
     void* d_stage = nullptr;             size_t stage_cap = 0;
     // Switches for measurements, read from the environment once, when the context is created.
     uint32_t group_waves = 4;           // waves per workgroup (RT_GROUP_WAVES: 1 .. 8, for measurements)
-    bool env_no_tile_order = false, env_no_slices = false, env_mesh_in_lds = false, env_no_probe = false;
+    bool env_no_tile_order = false, env_no_slices = false, env_mesh_in_lds = false, env_no_probe = false, env_no_tile_lists = false;
     uint32_t env_leaf = 0;               // RT_LEAF: triangles per tree leaf for every mesh (measurements); 0: chosen by mesh size
     float slice_share = 0.25f, slice_early = 0.5f;       // RT_SLICE_SHARE, RT_SLICE_EARLY (measurements)
     uint32_t slice_min_spp = 16u, slice_max = 16u;       // RT_SLICE_MIN_SPP, RT_SLICE_MAX
@@ -478,6 +497,7 @@ static int build_blob_impl(rt_ctx* ctx)
     ctx->layout = L;
     ctx->n_spheres = n_sph; ctx->n_boxes = n_box;
     ctx->blob_dirty = false;
+    ++ctx->scene_version;
     return RT_OK;
 }
 
@@ -545,6 +565,7 @@ int rt_create(rt_ctx** out, const rt_config* cfg)
     ctx->env_mesh_in_lds = env_on("RT_MESH_IN_LDS");
     if (const char* v = getenv("RT_LEAF")) { const int n = atoi(v); if (n >= 1 && n <= (int)rtd::TREE_LEAF && (n & (n - 1)) == 0) ctx->env_leaf = (uint32_t)n; }
     ctx->env_no_probe = env_on("RT_NO_PROBE");
+    ctx->env_no_tile_lists = env_on("RT_NO_TILE_LISTS");
     if (const char* v = getenv("RT_SLICE_SHARE")) { const float f = (float)atof(v); if (f > 0.0f) ctx->slice_share = f; }
     if (const char* v = getenv("RT_SLICE_EARLY")) { const float f = (float)atof(v); if (f > 0.0f) ctx->slice_early = f; }
     if (const char* v = getenv("RT_SLICE_MIN_SPP")) { const int n = atoi(v); if (n >= 1) ctx->slice_min_spp = (uint32_t)n; }
@@ -565,6 +586,7 @@ void rt_destroy(rt_ctx* ctx)
     (void)hipFree(ctx->d_stats);
     (void)hipFree(ctx->d_tile_cost);
     (void)hipFree(ctx->d_tile_order);
+    (void)hipFree(ctx->d_tile_lists);
     (void)hipFree(ctx->d_stage);
     delete ctx;
 }
@@ -574,7 +596,13 @@ const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g
 int rt_set_stream(rt_ctx* ctx, void* hip_stream)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;
-    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (s != ctx->stream) {
+        // what the old stream is still writing (the launch plan, the camera rays' candidate lists) the new one will read
+        RT_HIP(ctx, hipSetDevice(ctx->device));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ctx->stream = s;
     return RT_OK;
 }
 
@@ -642,6 +670,7 @@ int rt_bind_accum(rt_ctx* ctx, void* device_words, uint32_t width, uint32_t heig
     ctx->d_accum_ext = static_cast<uint32_t*>(device_words);
     ctx->width = width; ctx->height = height;
     ctx->accum_samples = 0;
+    ctx->discard_pending = false;        // the new buffer is used as it is
     return RT_OK;
 }
 
@@ -769,8 +798,40 @@ static int make_plan(rt_ctx* ctx, uint32_t* cost, uint32_t* order, uint32_t n_ti
     return RT_OK;
 }
 
+// The candidate lists of the camera rays for this launch's tiling (nullptr: the scene has no use for them, or they are
+// switched off): made when the scene, the camera, the frame size or the row shard changed since they were last made.
+static int ensure_lists(rt_ctx* ctx, const rtd::TraceParams& P, const uint32_t** out)
+{
+    *out = nullptr;
+    // (the masks of a list hold 32 spheres and 32 boxes: a scene beyond them has no lists)
+    if (ctx->env_no_tile_lists || P.rng_mode != 0 || (P.flags & RT_FLAG_LITERAL_GEOMETRY) != 0u || P.scene.n_sph > 32u || P.scene.n_box > 32u ||
+        (P.scene.n_sph < 2u && P.scene.n_box == 0 && P.scene.n_tris == 0)) return RT_OK;
+    rt_ctx::ListKey key{};
+    memcpy(key.cam, P.cam, sizeof key.cam);
+    key.width = P.width; key.height = P.height; key.sample_mode = P.sample_mode; key.grid_n = P.grid_n;
+    key.shard_index = P.shard_index; key.shard_count = P.shard_count; key.band_rows = P.band_rows; key.owned_rows = P.owned_rows;
+    key.tiles_x = P.tiles_x; key.tiles_y = P.tiles_y; key.scene_version = ctx->scene_version;
+    const uint32_t n_wt = 4u * P.tiles_x * P.tiles_y;
+    if (n_wt > ctx->lists_cap) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        RT_HIP(ctx, hipFree(ctx->d_tile_lists)); ctx->d_tile_lists = nullptr; ctx->lists_cap = 0; ctx->lists_valid = false;
+        RT_HIP(ctx, hipMalloc(&ctx->d_tile_lists, sizeof(uint32_t) * rtd::TLIST_WORDS * (size_t)n_wt));
+        ctx->lists_cap = n_wt;
+    }
+    if (!ctx->lists_valid || memcmp(&key, &ctx->lists_key, sizeof key) != 0) {
+        RT_HIP(ctx, rtd::launch_tile_lists(ctx->stream, P, ctx->d_blob, ctx->d_tile_lists));
+        ctx->lists_key = key; ctx->lists_valid = true;
+    }
+    *out = ctx->d_tile_lists;
+    return RT_OK;
+}
+
 // A render call of at least this many samples per pixel that has no plan yet traces its first PROBE_SPP samples in
 // the built-in order, makes the plan from what the tiles cost there, and traces the rest by that plan.
+// Primary steps trade steps for work: a wave takes more, cheaper steps.  That pays while the machine is kept full; a
+// launch of a few samples per pixel is over before it is (measured on 512 x 512, 16 samples: 58 us without the
+// lists, 77 us with them), so such a launch traces without them.
+constexpr uint32_t LISTS_MIN_SPP = 32u;
 constexpr uint32_t PROBE_MIN_SPP = 64u, PROBE_SPP = 8u;      // measured: 16 -> 8 takes the cold frame of the mesh scene from 17.0 to 16.4 ms, of the 4 968-triangle mesh from 31.5 to 26.7
 
 // Traces samples [P.first_sample, P.first_sample + P.spp) into `accum`: one launch by the plan in `order` (have_plan),
@@ -779,7 +840,7 @@ constexpr uint32_t PROBE_MIN_SPP = 64u, PROBE_SPP = 8u;      // measured: 16 -> 
 // plan_after the plan of the next frame is made from it and left in `order` (and `cost` is zero again).
 // *plan_units: in, the workgroups of the plan in `order`; out, those of the plan left there.
 static int trace_frame(rt_ctx* ctx, rtd::TraceParams P, uint32_t* accum, int mode, uint32_t* cost, uint32_t* order,
-                       bool have_plan, bool allow_probe, bool plan_after, uint32_t* plan_units, int32_t* d_timeline)
+                       bool have_plan, bool allow_probe, bool plan_after, uint32_t* plan_units, int32_t* d_timeline, const uint32_t* lists)
 {
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
     const uint32_t spp_all = P.spp;
@@ -787,22 +848,31 @@ static int trace_frame(rt_ctx* ctx, rtd::TraceParams P, uint32_t* accum, int mod
         rtd::TraceParams probe = P;
         const uint32_t probe_spp = ctx->probe_spp ? ctx->probe_spp : PROBE_SPP;
         probe.spp = probe_spp;
+        probe.resolve_out = nullptr;                       // the frame ends with the launch after this one
+        P.overwrite = 0u;                                  // ... which adds to what this one stores
         RT_HIP(ctx, rtd::launch_trace((int)ctx->cfg.semantics, mode, ctx->stream, probe, ctx->d_blob, accum, ctx->d_stats, nullptr, nullptr,
-                                      nullptr, cost, n_tiles));
+                                      nullptr, cost, n_tiles, probe_spp >= LISTS_MIN_SPP ? lists : nullptr));
         P.first_sample += probe_spp; P.spp -= probe_spp;
         int rc = make_plan(ctx, cost, order, n_tiles, P.spp, plan_units);
         if (rc) return rc;
         have_plan = true;
+        // The plan just made may cut tiles into slices (only the device knows): their sums go through atomics, which
+        // the resolve in the launch cannot follow.  The caller resolves afterwards (see render_impl).
+        if (*plan_units != n_tiles) P.resolve_out = nullptr;
     }
     RT_HIP(ctx, rtd::launch_trace((int)ctx->cfg.semantics, mode, ctx->stream, P, ctx->d_blob, accum, ctx->d_stats, d_timeline, nullptr,
-                                  have_plan ? order : nullptr, cost, have_plan ? *plan_units : n_tiles));
+                                  have_plan ? order : nullptr, cost, have_plan ? *plan_units : n_tiles, P.spp >= LISTS_MIN_SPP ? lists : nullptr));
     if (plan_after) return make_plan(ctx, cost, order, n_tiles, spp_all, plan_units);
     return RT_OK;
 }
 
+constexpr uint32_t REPLAN_EVERY = 32u;
+
+struct ResolveInto { float* rgba_device; int gamma_sqrt, flip_rows; };
+
 static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth,
                        uint64_t seed, uint32_t first_sample, uint32_t grid_n, rt_stats* stats,
-                       int32_t* timeline_host = nullptr, uint32_t timeline_waves = 0)
+                       int32_t* timeline_host = nullptr, uint32_t timeline_waves = 0, const ResolveInto* resolve = nullptr)
 {
     if (!ctx) return RT_ERR_INVALID_ARG;
     RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -814,6 +884,13 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
     rc = ensure_accum(ctx, width, height);
     if (rc) return rc;
     if (stats) RT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * rtd::ST_COUNT, ctx->stream));
+    bool resolved_in_launch = false;
+    bool discard = ctx->discard_pending;                 // the accumulator's contents are dropped (rt_discard_accum)
+    if (discard) ctx->accum_samples = 0;
+    if (discard && !(spp > 0 && P.owned_rows > 0)) {
+        RT_HIP(ctx, hipMemsetAsync(accum_ptr(ctx), 0, (size_t)ctx->width * ctx->height * 16u, ctx->stream));
+        ctx->discard_pending = false;
+    }
     if (spp > 0 && P.owned_rows > 0) {
         rc = ensure_tiles(ctx, P);
         if (rc) return rc;
@@ -827,6 +904,26 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
                                (ctx->plan_units == n_tiles || (spp < (1u << 24) && slices_allowed(ctx, spp) >= ctx->plan_max_slices));
         if (!have_plan) RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, sizeof(uint32_t) * n_tiles, ctx->stream));
         uint32_t plan_units = have_plan ? ctx->plan_units : n_tiles;
+        // The same view as the plan was made from: the plan stays and this call collects no costs (a sphere scene's
+        // plan never changes; a plan of a mesh scene only orders and cuts the tiles, any plan gives the same words).
+        rt_ctx::PlanView view{};
+        memcpy(view.cam, P.cam, sizeof view.cam);
+        view.scene_version = ctx->scene_version; view.spp = spp; view.max_depth = max_depth;
+        view.shard_index = P.shard_index; view.shard_count = P.shard_count; view.band_rows = P.band_rows;
+        const bool replan = !have_plan || memcmp(&view, &ctx->plan_view, sizeof view) != 0 || ctx->plan_age + 1u >= REPLAN_EVERY ||
+                            stats != nullptr || timeline_host != nullptr;
+        // A launch whose plan cuts no tile (every pixel's sum is formed by one lane) can start from zero instead of
+        // from the accumulator, and can end with the frame's resolve.
+        const bool first_sliced = have_plan && plan_units != n_tiles;
+        if (discard) {
+            if (first_sliced) RT_HIP(ctx, hipMemsetAsync(accum_ptr(ctx), 0, (size_t)ctx->width * ctx->height * 16u, ctx->stream));
+            else P.overwrite = 1u;
+            ctx->discard_pending = false;
+        }
+        if (resolve && !first_sliced && !timeline_host) {
+            P.resolve_out = resolve->rgba_device; P.resolve_samples = ctx->accum_samples + spp;
+            P.resolve_gamma = resolve->gamma_sqrt ? 1u : 0u; P.resolve_flip = resolve->flip_rows ? 1u : 0u;
+        }
         int32_t* d_timeline = nullptr;
         if (timeline_host) {
             if (timeline_waves < 4u * plan_units) return fail(ctx, RT_ERR_INVALID_ARG, "timeline buffer holds %u waves, the launch has %u", timeline_waves, 4u * plan_units);
@@ -835,8 +932,15 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
             if (me != hipSuccess) { (void)hipFree(d_timeline); RT_HIP(ctx, me); }
         }
         const uint32_t launched = plan_units;
-        rc = trace_frame(ctx, P, accum_ptr(ctx), stats ? 1 : 0, ctx->d_tile_cost, ctx->d_tile_order, have_plan,
-                         !timeline_host && !ctx->env_no_probe && !ctx->env_no_tile_order, true, &plan_units, d_timeline);
+        const uint32_t* lists = nullptr;
+        rc = ensure_lists(ctx, P, &lists);
+        if (rc) { if (d_timeline) (void)hipFree(d_timeline); return rc; }
+        const bool will_probe = !have_plan && !timeline_host && !ctx->env_no_probe && !ctx->env_no_tile_order && spp >= PROBE_MIN_SPP;
+        rc = trace_frame(ctx, P, accum_ptr(ctx), stats ? 1 : 0, replan ? ctx->d_tile_cost : nullptr, ctx->d_tile_order, have_plan,
+                         !timeline_host && !ctx->env_no_probe && !ctx->env_no_tile_order, replan, &plan_units, d_timeline, lists);
+        // resolved by the launch itself unless a probe's plan may have cut tiles (trace_frame then dropped the request)
+        resolved_in_launch = P.resolve_out != nullptr && !(will_probe && slices_allowed(ctx, spp - (ctx->probe_spp ? ctx->probe_spp : PROBE_SPP)) > 1u);
+        if (replan) { ctx->plan_view = view; ctx->plan_age = 0; } else ++ctx->plan_age;
         if (rc) { if (d_timeline) (void)hipFree(d_timeline); return rc; }
         hipError_t le = hipSuccess;
         if (d_timeline) {
@@ -850,6 +954,11 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         ctx->plan_max_slices = plan_units == n_tiles ? 1u : slices_allowed(ctx, spp);
     }
     ctx->accum_samples += spp;
+    if (resolve && !resolved_in_launch) {
+        if (ctx->accum_samples == 0) return fail(ctx, RT_ERR_STATE, "resolve: nothing has been rendered");
+        RT_HIP(ctx, rtd::launch_resolve((int)ctx->cfg.semantics, ctx->stream, accum_ptr(ctx), resolve->rgba_device, ctx->width, ctx->height,
+                                        ctx->accum_samples, resolve->gamma_sqrt, resolve->flip_rows));
+    }
     if (stats) {
         unsigned long long h[rtd::ST_COUNT];
         RT_HIP(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
@@ -870,6 +979,8 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         stats->work_units = h[rtd::ST_UNITS];
         stats->box_tests_done = h[rtd::ST_BOX_TESTS];
         stats->box_bound_tests_done = h[rtd::ST_BOX_BOUNDS];
+        stats->sphere_tests_done = h[rtd::ST_SPHERE_TESTS];
+        stats->primary_steps = h[rtd::ST_PRIMARY_STEPS];
     }
     return RT_OK;
 }
@@ -897,13 +1008,40 @@ int rt_render_noalloc(rt_ctx* ctx, void* accum_device, uint32_t width, uint32_t 
     uint32_t* const order = ctx->d_scratch + RT_NOALLOC_MAX_TILES;
     RT_HIP(ctx, hipMemsetAsync(cost, 0, sizeof(uint32_t) * n_tiles, ctx->stream));
     uint32_t plan_units = n_tiles;
-    return trace_frame(ctx, P, static_cast<uint32_t*>(accum_device), 0, cost, order, false, true, false, &plan_units, nullptr);
+    // The candidate lists of the camera rays live in memory rt_render allocates: this call takes those an earlier
+    // rt_render of the same view left, or traces without them (the same words, more slowly on scenes with boxes or a mesh).
+    const uint32_t* lists = nullptr;
+    if (ctx->lists_valid && !ctx->env_no_tile_lists && P.rng_mode == 0) {
+        rt_ctx::ListKey key{};
+        memcpy(key.cam, P.cam, sizeof key.cam);
+        key.width = P.width; key.height = P.height; key.sample_mode = P.sample_mode; key.grid_n = P.grid_n;
+        key.shard_index = P.shard_index; key.shard_count = P.shard_count; key.band_rows = P.band_rows; key.owned_rows = P.owned_rows;
+        key.tiles_x = P.tiles_x; key.tiles_y = P.tiles_y; key.scene_version = ctx->scene_version;
+        if (memcmp(&key, &ctx->lists_key, sizeof key) == 0) lists = ctx->d_tile_lists;
+    }
+    return trace_frame(ctx, P, static_cast<uint32_t*>(accum_device), 0, cost, order, false, true, false, &plan_units, nullptr, lists);
 }
 
 int rt_render(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth,
               uint64_t seed, uint32_t first_sample, uint32_t grid_n)
 {
     return render_impl(ctx, width, height, spp, max_depth, seed, first_sample, grid_n, nullptr);
+}
+
+int rt_render_resolved(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth,
+                       uint64_t seed, uint32_t first_sample, uint32_t grid_n, float* rgba_device, int gamma_sqrt, int flip_rows)
+{
+    if (ctx && !rgba_device) return fail(ctx, RT_ERR_INVALID_ARG, "rt_render_resolved: output is NULL");
+    const ResolveInto r = { rgba_device, gamma_sqrt, flip_rows };
+    return render_impl(ctx, width, height, spp, max_depth, seed, first_sample, grid_n, nullptr, nullptr, 0, &r);
+}
+
+int rt_discard_accum(rt_ctx* ctx)
+{
+    if (!ctx) return RT_ERR_INVALID_ARG;
+    ctx->discard_pending = true;
+    ctx->accum_samples = 0;
+    return RT_OK;
 }
 
 int rt_render_stats(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_depth,
@@ -942,6 +1080,7 @@ int rt_reset_accum(rt_ctx* ctx)
     if (accum_ptr(ctx))
         RT_HIP(ctx, hipMemsetAsync(accum_ptr(ctx), 0, (size_t)ctx->width * ctx->height * 16u, ctx->stream));
     ctx->accum_samples = 0;
+    ctx->discard_pending = false;
     return RT_OK;
 }
 
@@ -1042,7 +1181,7 @@ int rt_trace_debug(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t max_de
     RT_HIP(ctx, rtd::launch_trace_fill(ctx->stream, d_hit, d_mat, n));
     // accum is not touched by a TRACE launch; pass any valid pointer.
     RT_HIP(ctx, rtd::launch_trace((int)ctx->cfg.semantics, 2, ctx->stream, P, ctx->d_blob, reinterpret_cast<uint32_t*>(d_hit), ctx->d_stats,
-                                  d_hit, d_mat, nullptr, nullptr, P.tiles_x * P.tiles_y));
+                                  d_hit, d_mat, nullptr, nullptr, P.tiles_x * P.tiles_y, nullptr));
     RT_HIP(ctx, hipMemcpyAsync(hit_index_host, d_hit, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipMemcpyAsync(material_id_host, d_mat, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -89,11 +89,33 @@ struct TraceParams {
     uint32_t rng_mode;         // 0 counter hash, 1 the shader's random() (RayTracing.glsl:44-51)
     uint32_t glsl_seed32;      // low word of the seed: the shader's `time` is (this + frame) / 10000
     float    inv_w, inv_h;     // 1 / width, 1 / height (RayTracing.glsl:9 divides the invocation id by them)
+    uint32_t overwrite;        // 1: the accumulator's contents are dropped — sums start at zero and are stored, not added (a launch without sliced tiles)
+    // The frame's resolve as the launch's last step (a launch without sliced tiles that ends the frame): every lane
+    // writes its pixel's mean as resolve_kernel would.  resolve_out = nullptr: no resolve.
+    uint32_t resolve_samples, resolve_gamma, resolve_flip;
+    float*   resolve_out;
     SceneLayout scene;
 };
 
 // Slots of the statistics block (uint64 each).
-enum { ST_SAMPLES = 0, ST_SEGMENTS, ST_DIFFUSE, ST_SPECULAR, ST_TERMINAL, ST_TRI_TESTS, ST_NODE_TESTS, ST_WAVE_ITERS, ST_UNITS, ST_BOX_TESTS, ST_BOX_BOUNDS, ST_COUNT };
+enum { ST_SAMPLES = 0, ST_SEGMENTS, ST_DIFFUSE, ST_SPECULAR, ST_TERMINAL, ST_TRI_TESTS, ST_NODE_TESTS, ST_WAVE_ITERS, ST_UNITS, ST_BOX_TESTS, ST_BOX_BOUNDS,
+       ST_SPHERE_TESTS, ST_PRIMARY_STEPS, ST_COUNT };
+
+// Candidate lists of the camera rays, one record per 8x8-pixel wave tile (tile_lists_kernel makes them once per scene,
+// camera and frame size; trace_kernel's "primary steps" read them): every primitive that a camera ray through the
+// tile could be accepted by — conservatively: whatever touches the pyramid from the eye through the tile.
+//   word 0: spheres, bit s = sphere s in upload order among the spheres (scenes of up to 32)
+//   word 1: boxes, bit b likewise (up to 32)
+//   word 2: number of tree leaves that follow, or TLIST_NONE: no list for this tile (more leaves than fit, or a scene
+//           beyond the masks) — its waves then trace camera rays like any others
+//   word 3..: the leaves
+constexpr uint32_t TLIST_WORDS = 32u, TLIST_MAX_LEAVES = TLIST_WORDS - 3u, TLIST_NONE = 0xffffffffu;
+// A wave takes a primary step — only its lanes that are about to trace a camera ray take part, and they test the
+// tile's candidates instead of walking the scene — when all its live lanes are such, or at least this many.
+#ifndef RT_PSTEP_MIN
+#define RT_PSTEP_MIN 24
+#endif
+constexpr uint32_t PSTEP_MIN = RT_PSTEP_MIN;
 
 constexpr int TILE_W = 16;     // pixels per workgroup in x (two 8-wide wave tiles)
 constexpr int TILE_H = 16;     // and in y

@@ -63,9 +63,12 @@ namespace rtd {
 #define RT_PHASE_MARK_(k) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); phase_clk[k] += now_ - phase_t; phase_t = now_; }
 // RT_PHASE_CLOCKS=3: the triangle tree alone: everything else / the walk by the whole wave and the queueing / the
 // passes over queued nodes / the passes over queued leaves.
+// RT_PHASE_CLOCKS=4: primary steps (all of them) / the closest hit of the other steps / their rest; the fourth word
+// counts the primary steps (x 16).
 #define RT_PHASE_MARK(k)
 #define RT_PHASE_MARK2(k)
 #define RT_PHASE_MARK3(k)
+#define RT_PHASE_MARK4(k)
 #if RT_PHASE_CLOCKS == 1
 #undef RT_PHASE_MARK
 #define RT_PHASE_MARK(k) RT_PHASE_MARK_(k)
@@ -75,12 +78,25 @@ namespace rtd {
 #elif RT_PHASE_CLOCKS == 3
 #undef RT_PHASE_MARK3
 #define RT_PHASE_MARK3(k) RT_PHASE_MARK_(k)
+#elif RT_PHASE_CLOCKS == 4
+#undef RT_PHASE_MARK4
+#define RT_PHASE_MARK4(k) RT_PHASE_MARK_(k)
+#elif RT_PHASE_CLOCKS == 5
+// the four phases of RT_PHASE_CLOCKS=1, over the steps that are not primary steps
+#undef RT_PHASE_MARK
+#define RT_PHASE_MARK(k) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); if (!pstep) phase_clk[k] += now_ - phase_t; phase_t = now_; }
+#endif
+// Primary steps (see trace_kernel): -DRT_PSTEP=0 builds without them.
+#ifndef RT_PSTEP
+#define RT_PSTEP 1
 #endif
 struct V3 { float x, y, z; };
 constexpr uint32_t WORK_NONE = 0xffffffffu;      // a plan entry without work
 
 #define RT_DEV static __device__ __forceinline__
 
+// the first enabled lane of the wave (counts one per wave whatever the lanes taking part)
+RT_DEV bool lane_is_first() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(__ballot(1)); }
 RT_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 RT_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 RT_DEV V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
@@ -560,6 +576,24 @@ RT_DEV uint32_t quantise(float c)
     return q;
 }
 
+// One pixel's mean: rayTracer.h:105 (sum / totalRays, optional cwiseSqrt) and PixelConversion.glsl:17-20 (uint sum /
+// (255 * samples)); alpha = 1.
+template <int SEM>
+RT_DEV float4 resolve_pixel(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t samples, bool gamma_sqrt)
+{
+    float4 v;
+    if (SEM == 0) {
+        const float ns = (float)samples;
+        v.x = __uint_as_float(a0) / ns; v.y = __uint_as_float(a1) / ns; v.z = __uint_as_float(a2) / ns;
+    } else {
+        const float den = 255.0f * (float)samples;
+        v.x = (float)a0 / den; v.y = (float)a1 / den; v.z = (float)a2 / den;
+    }
+    if (gamma_sqrt) { v.x = __builtin_sqrtf(v.x); v.y = __builtin_sqrtf(v.y); v.z = __builtin_sqrtf(v.z); }
+    v.w = 1.0f;
+    return v;
+}
+
 // -------------------------------------------------------------- the tracer
 // SEM 0: rules of src/cpu_version (rayTracer.h:110-132, scene.h:39-109).
 // SEM 1: rules of RayTracing.glsl:233-288.
@@ -568,7 +602,8 @@ RT_DEV uint32_t quantise(float c)
 // materials or a colour per triangle, or the context asks for the reference's normalised-Gaussian sphere sampler (kept out of the other instances, whose registers and issue slots they
 // would cost: 12 % on the four-sphere scene); bit 3: draws come from the
 // shader's own random() instead of the counter hash; bit 4 (CPU rules, spheres and cubes only): the geometry in the
-// reference's literal arithmetic, see LIT below.  MODE 0: render.  MODE 1: render and count work.  MODE 2:
+// reference's literal arithmetic, see LIT below; bit 5 (counter hash, recipe arithmetic): camera rays are traced in
+// steps of their own from their tile's candidate list, see PSTEP below.  MODE 0: render.  MODE 1: render and count work.  MODE 2:
 // follow one sample, record hit and material ids, leave the accumulator alone.
 //
 // One loop iteration = one ray segment of every live lane: closest hit, then
@@ -589,7 +624,8 @@ void trace_kernel(const TraceParams P,
                   int32_t* __restrict__ trace_hit,
                   uint32_t* __restrict__ trace_mat,
                   const uint32_t* __restrict__ tile_order,
-                  uint32_t* __restrict__ tile_cost)
+                  uint32_t* __restrict__ tile_cost,
+                  const uint32_t* __restrict__ tile_lists)
 {
     constexpr bool STATS = MODE == 1, TRACE = MODE == 2;
     constexpr bool COST_CLOCK = RT_COST_CLOCK != 0;        // a tile's cost: shader clocks of its slowest wave, not loop iterations
@@ -605,10 +641,16 @@ void trace_kernel(const TraceParams P,
     static_assert(!LIT || (SEM == 0 && (GEO & 3) == 0 && (GEO & 8) == 0), "literal geometry: CPU rules, spheres and cubes, counter hash");
     constexpr bool HAS_QUEUES = (GEO & 3) != 0, TRI_GLOBAL = (GEO & 3) == 2, SPREAD_BOXES = HAS_QUEUES, HAS_CUBE = SEM == 0 && (GEO & 4) != 0, HAS_GLASS = (GEO & 4) != 0, HAS_TCOL = (GEO & 4) != 0, RNG_GLSL = (GEO & 8) != 0,
                    HAS_GAUSS = SEM == 0 && (GEO & 4) != 0 && (GEO & 8) == 0;
+    // Primary steps (below): instances with queues, whose closest hit is long.  Not with the shader's own stream, whose
+    // pooled restart reads its pixel's coordinates from the pixel's home lane, which a primary step may have left out.
+    // An instance of its own (GEO bit 5), launched when the scene has lists: the others keep their code as it was.
+    constexpr bool PSTEP = (GEO & 32) != 0;
+    static_assert(!PSTEP || (!RNG_GLSL && (GEO & 16) == 0), "primary steps: counter hash, recipe arithmetic");
     extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
-    uint32_t n_samples = 0, n_segments = 0, n_diffuse = 0, n_specular = 0, n_terminal = 0, n_tri = 0, n_node = 0, n_iterations = 0, n_box_test = 0, n_box_bound = 0;
+    uint32_t n_samples = 0, n_segments = 0, n_diffuse = 0, n_specular = 0, n_terminal = 0, n_tri = 0, n_node = 0, n_iterations = 0, n_box_test = 0, n_box_bound = 0,
+             n_sph_test = 0, n_psteps = 0;
 
     // One 8x8-pixel tile per wave, four waves (a 16x16 tile) per workgroup; workgroups start in
     // blockIdx order.  `work` is the plan made from the previous frame of this view (tile_plan_kernel):
@@ -659,7 +701,7 @@ void trace_kernel(const TraceParams P,
     // Running sums of this pixel: float for SEM 0, uint for SEM 1.
     uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
     uint32_t* const acc_ptr = accum + 4u * (size_t)pixel;
-    if (!TRACE && valid && n_slices == 1u) {
+    if (!TRACE && valid && n_slices == 1u && P.overwrite == 0u) {
         uint4 v = *reinterpret_cast<const uint4*>(acc_ptr);
         acc0 = v.x; acc1 = v.y; acc2 = v.z;
     }
@@ -778,11 +820,35 @@ void trace_kernel(const TraceParams P,
         pool_acc[lane] = 0u; pool_acc[64u + lane] = 0u; pool_acc[128u + lane] = 0u;
         pool_pix[lane] = make_float4(pc.x, pc.y, pc.z, __uint_as_float(h1));
     }
+    // Primary steps.  59 % of the mesh scene's ray segments are camera rays, and what a camera ray of this wave's 8x8
+    // tile can hit is known before the frame starts: the few primitives that touch the pyramid from the eye through
+    // the tile (tile_lists_kernel).  A camera ray that takes part in an ordinary iteration pays for the whole scene —
+    // every sphere, every box's bounds, the tree walk its bouncing neighbours cause.  So when all live lanes of the
+    // wave are about to trace a camera ray, or at least PSTEP_MIN of them, the wave takes a step for those lanes
+    // alone (the others wait one step): they test the tile's candidates directly, no bounds, no queues.  The
+    // candidates include every primitive whose test could accept such a ray, the closest hit is the same minimum
+    // of (distance, index): the same words.  A step with fewer camera rays is an ordinary iteration for everyone.
+    uint32_t pl_sph = 0u, pl_box = 0u, pl_n = TLIST_NONE;
+    const uint32_t* pl_leaves = nullptr;
+    if (PSTEP && tile_lists) {
+        const uint32_t wt = __builtin_amdgcn_readfirstlane((tile_y * 2u + (sub >> 1)) * (2u * P.tiles_x) + tile_x * 2u + (sub & 1u));
+        const uint32_t* const rec_ = tile_lists + (size_t)wt * TLIST_WORDS;
+        pl_sph = rec_[0]; pl_box = rec_[1]; pl_n = rec_[2]; pl_leaves = rec_ + 3;
+    }
+    const bool have_list = PSTEP && pl_n != TLIST_NONE;
 #if RT_PHASE_CLOCKS
     uint32_t phase_clk[4] = { 0u, 0u, 0u, 0u }, phase_t = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
     while (alive) {
         ++iterations;
+        bool pstep = false;                                           // wave-uniform
+        bool ended_now = false;                                       // POOL: this lane's path ended in this step
+        if (PSTEP && have_list) {
+            const uint32_t n_all = (uint32_t)__popcll(__ballot(1)), n_first = (uint32_t)__popcll(__ballot(bounce == 0u));
+            pstep = n_first == n_all || n_first >= PSTEP_MIN;
+        }
+        if (!pstep || bounce == 0u) {
+        if (STATS && pstep && lane_is_first()) ++n_psteps;
         // ---- closest hit: Scene::hit (scene.h:232-255) /
         //      getClosestShapeIndex + getClosestTriangleIndex (glsl:206-231).
         //      One running (key, id) serves shapes and triangles: shapes come first
@@ -822,8 +888,17 @@ void trace_kernel(const TraceParams P,
                 }
             }
             lit_t = best.id == NONE ? 0.0f : (float)best_t;
+            if (STATS) n_sph_test += n_sph;
         }
-        for (uint32_t c = 0; !LIT && c < n_chunks; ++c) {
+        if (PSTEP && pstep) {
+            // the tile's candidate spheres, in upload order (a later one replaces the best only by a strictly smaller key)
+            for (uint32_t m = pl_sph; m != 0u; m &= m - 1u) {
+                const uint32_t i = (uint32_t)__builtin_ctz(m);
+                test_sphere<SEM>(sph[i], reinterpret_cast<const uint32_t*>(sid)[i], o, d, best);
+                if (STATS) ++n_sph_test;
+            }
+        }
+        for (uint32_t c = 0; !LIT && !(PSTEP && pstep) && c < n_chunks; ++c) {
             const float4 s0 = sph[4u * c], s1 = sph[4u * c + 1u], s2 = sph[4u * c + 2u], s3 = sph[4u * c + 3u];
             const float4 ids = sid[c];
             test_sphere<SEM>(s0, __float_as_uint(ids.x), o, d, best);
@@ -832,8 +907,9 @@ void trace_kernel(const TraceParams P,
             test_sphere<SEM>(s3, __float_as_uint(ids.w), o, d, best);
         }
         // the one to three spheres behind the last whole chunk, one at a time: the padding of their chunk is not tested
-        for (uint32_t i = 4u * n_chunks; !LIT && i < n_sph; ++i)
+        for (uint32_t i = 4u * n_chunks; !LIT && !(PSTEP && pstep) && i < n_sph; ++i)
             test_sphere<SEM>(sph[i], reinterpret_cast<const uint32_t*>(sid)[i], o, d, best);
+        if (STATS && !LIT && !(PSTEP && pstep)) n_sph_test += n_sph;
         if (!LIT && (HAS_QUEUES || HAS_CUBE)) best.key = (best.id == NONE) ? Window<SEM>::far - 1u - Window<SEM>::tmin : best.key;
         RT_PHASE_MARK(0)
         // The lanes still tracing, and this lane's place among them: they share the queued tests.
@@ -846,7 +922,15 @@ void trace_kernel(const TraceParams P,
         const bool spread = HAS_QUEUES && n_live >= 16u;             // fewer live lanes: every test as a wave
         // Boxes.  The full test is long (three reciprocals, three candidate points); a lane needs it only for a box
         // whose bounds its ray touches (a slab test).  Those (lane, box) pairs are queued and tested one lane per pair.
-        if (SPREAD_BOXES && spread && cull) {
+        if (PSTEP && pstep) {
+            // the tile's candidate boxes: the exact test by every lane of the step, no bounds first
+            for (uint32_t m = pl_box; m != 0u; m &= m - 1u) {
+                const uint32_t i = (uint32_t)__builtin_ctz(m);
+                const float4 bx = box[3u * i], bx1 = box[3u * i + 1u];
+                take_if_closer(best, __float_as_uint(hit_box(bx, bx1.y, bx1.z, o, d)) - Window<SEM>::tmin, __float_as_uint(bx1.x));
+                if (STATS) ++n_box_test;
+            }
+        } else if (SPREAD_BOXES && spread && cull) {
             uint32_t bq_len = 0u;                                 // wave-uniform
             // 1 / d for the slab test of the bounds: hardware reciprocals (within an ulp; a zero component gives an
             // infinity) — the bounds carry the slack for that, and decide nothing but who runs the exact test.
@@ -925,7 +1009,20 @@ void trace_kernel(const TraceParams P,
         // triangle, each fetching the ray of the pair's lane across the wave.  A crossing goes to the slot of the
         // ray's lane by an atomic minimum on (key, id) — the same order-independent minimum as everywhere else —
         // and every lane folds its slot into its closest hit when the walk is over.
-        if (HAS_QUEUES) {
+        if (PSTEP && pstep) {
+            // the tile's candidate leaves: their triangles by every lane of the step
+            const uint32_t leaf_shift = L.leaf_shift, leaf_size = 1u << leaf_shift;
+            for (uint32_t k = 0; k < pl_n; ++k) {
+                const uint32_t first = pl_leaves[k] << leaf_shift;
+                for (uint32_t j = 0; j < leaf_size; ++j) {
+                    const float4* const t4 = tri + 4u * (first + j);
+                    float4 w0 = t4[0], w1 = t4[1], w2 = t4[2], w3 = t4[3];
+                    if (!TRI_GLOBAL) asm volatile("" : "+v"(w2.w), "+v"(w3.w));          // whole 16-byte LDS reads
+                    test_triangle<SEM>(w0, w1, w2, w3, n_shapes, o, d, best);
+                }
+                if (STATS) n_tri += leaf_size;
+            }
+        } else if (HAS_QUEUES) {
             const uint32_t leaf_shift = L.leaf_shift, leaf_size = 1u << leaf_shift;     // triangles per leaf: chosen per mesh
             const uint32_t per_pass = n_live >> leaf_shift;       // pairs one pass takes: one lane per triangle of the leaf
             uint32_t q_head = 0u, q_len = 0u;                     // wave-uniform
@@ -1070,6 +1167,7 @@ void trace_kernel(const TraceParams P,
         RT_PHASE_MARK(2)
         RT_PHASE_MARK3(1)
         RT_PHASE_MARK2(0)
+        RT_PHASE_MARK4(pstep ? 0 : 1)
         const uint32_t best_key = best.key, best_id = best.id;
         if (STATS) { ++n_segments; }
 
@@ -1157,7 +1255,7 @@ void trace_kernel(const TraceParams P,
         if (POOL) {
             const unsigned long long em = __ballot(ended);
             new_item = pool_on ? next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u)) : item + 64u;
-            next_item += (uint32_t)__popcll(em);
+            ended_now = ended;                                       // next_item moves on below, in every lane of the wave
         }
         if (ended) {
             if (STATS) ++n_terminal;
@@ -1166,9 +1264,13 @@ void trace_kernel(const TraceParams P,
                 acc1 = __float_as_uint(__uint_as_float(acc1) + color.y);
                 acc2 = __float_as_uint(__uint_as_float(acc2) + color.z);
             } else if (POOL) {
-                atomicAdd(&pool_acc[cur_p], quantise(color.x));            // glsl:301-307
-                atomicAdd(&pool_acc[64u + cur_p], quantise(color.y));
-                atomicAdd(&pool_acc[128u + cur_p], quantise(color.z));
+                // glsl:301-307.  Most paths end in the dark (a miss, the last segment): they add nothing.
+                const uint32_t q0 = quantise(color.x), q1 = quantise(color.y), q2 = quantise(color.z);
+                if ((q0 | q1 | q2) != 0u) {
+                    atomicAdd(&pool_acc[cur_p], q0);
+                    atomicAdd(&pool_acc[64u + cur_p], q1);
+                    atomicAdd(&pool_acc[128u + cur_p], q2);
+                }
             } else {
                 acc0 += quantise(color.x);                                 // glsl:301-307
                 acc1 += quantise(color.y);
@@ -1292,6 +1394,13 @@ void trace_kernel(const TraceParams P,
         }
         RT_PHASE_MARK(3)
         RT_PHASE_MARK2(3)
+        }   // lanes of this step
+        RT_PHASE_MARK4(pstep ? 0 : 2)
+#if RT_PHASE_CLOCKS == 4
+        if (pstep) phase_clk[3] += 16u;
+#endif
+        // The pool's next item is one number for the wave: every lane keeps it, also those a primary step left out.
+        if (POOL) next_item += (uint32_t)__popcll(__ballot(ended_now));
     }
 
     if (!TRACE && valid) {
@@ -1301,6 +1410,12 @@ void trace_kernel(const TraceParams P,
         } else {
             uint4 v; v.x = acc0; v.y = acc1; v.z = acc2; v.w = 0u;
             *reinterpret_cast<uint4*>(acc_ptr) = v;
+            if (P.resolve_out != nullptr) {
+                // the frame ends with this launch: its resolve here, from the sums still in registers
+                const uint32_t oy = P.resolve_flip ? P.height - 1u - gy : gy;
+                *reinterpret_cast<float4*>(P.resolve_out + 4u * ((size_t)oy * P.width + gx)) =
+                    resolve_pixel<SEM>(acc0, acc1, acc2, P.resolve_samples, P.resolve_gamma != 0u);
+            }
         }
     }
     // What this tile cost, for the next frame's launch order: the longest of its four waves' loops.
@@ -1331,7 +1446,7 @@ void trace_kernel(const TraceParams P,
     if (STATS) {
         // Sum over the wave with cross-lane shuffles, one atomic per wave and counter.
         uint32_t c[ST_COUNT] = { n_samples, n_segments, n_diffuse, n_specular, n_terminal, n_tri, n_node, (lane == 0u) ? n_iterations : 0u,
-                                 (lane == 0u && (q & 3u) == 0u) ? 1u : 0u, n_box_test, n_box_bound };
+                                 (lane == 0u && (q & 3u) == 0u) ? 1u : 0u, n_box_test, n_box_bound, n_sph_test, n_psteps };
 #pragma unroll
         for (int k = 0; k < ST_COUNT; ++k) {
             unsigned long long v = c[k];
@@ -1431,6 +1546,137 @@ void tile_plan_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ work, 
     for (uint32_t i = tid; i < n; i += 1024u) cost[i] = 0u;
 }
 
+// The candidate lists of the camera rays (rt_device.h, TLIST_*): one thread per 8x8-pixel wave tile of the launch.
+// A camera ray starts on the image plane inside its pixel's square (RayTracing.glsl:293-296, rayTracer.h:92-101) and
+// points away from the eye (glsl:297, rayTracer.h:100), so every camera ray of a tile lies in the pyramid from the eye
+// through the tile's rectangle on the image plane.  A primitive is a candidate when its bound reaches into that
+// pyramid: for each of the four side planes, the bound's support point along the plane's inward normal is not
+// outside by more than `slack`.  The slack covers what the tracer's own arithmetic can move a ray by (the rounding of
+// the origin on the plane, a few units of 2^-24 of the camera's coordinates, seen from the eye at the distance of the
+// plane) and, for the spheres, what the rounding of Sphere::hit's discriminant can still accept (about 2^-22 d^2 / r
+// beside a sphere of radius r at distance d); the tree's bounds and the boxes' bounds carry the slack of their own
+// tests already.  Computed in double: the lists must never miss, and the kernel runs once per camera.
+__global__ __launch_bounds__(64)
+void tile_lists_kernel(const TraceParams P, const float4* __restrict__ blob, uint32_t* __restrict__ lists)
+{
+    const uint32_t wt = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t wtx_n = 2u * P.tiles_x, n_wt = wtx_n * 2u * P.tiles_y;
+    if (wt >= n_wt) return;
+    uint32_t* const rec = lists + (size_t)wt * TLIST_WORDS;
+    const uint32_t wty = wt / wtx_n, wtx = wt - wty * wtx_n;
+    // image rows of the tile's eight owned rows (a row shard's bands need not be multiples of eight)
+    uint32_t gy_lo = 0xffffffffu, gy_hi = 0u;
+    for (uint32_t r = 0; r < 8u; ++r) {
+        const uint32_t row = wty * 8u + r;
+        if (row >= P.owned_rows) break;
+        const uint32_t band = row / P.band_rows;
+        const uint32_t gy = (band * P.shard_count + P.shard_index) * P.band_rows + (row - band * P.band_rows);
+        if (gy >= P.height) continue;
+        gy_lo = min(gy_lo, gy); gy_hi = max(gy_hi, gy);
+    }
+    const uint32_t gx_lo = wtx * 8u;
+    rec[0] = 0u; rec[1] = 0u; rec[2] = TLIST_NONE;
+    if (gy_lo > gy_hi || gx_lo >= P.width) return;                 // no pixel: no wave reads this record
+    const SceneLayout& L = P.scene;
+    if (L.n_sph > 32u || L.n_box > 32u) return;                    // beyond the masks: no lists for this scene
+
+    // the tile's rectangle in pixel units, a little wider than its pixels; the grid as written lets the x offset
+    // accumulate beyond the pixel (rayTracer.h:98-99): by less than grid_n / 2 pixels
+    const double margin = 1.0 / 64.0;
+    const double x0 = (double)gx_lo - margin, x1 = (double)min(gx_lo + 8u, P.width) + margin + (P.sample_mode == 2u ? 0.5 * (double)P.grid_n + 1.0 : 0.0);
+    const double y0 = (double)gy_lo - margin, y1 = (double)gy_hi + 1.0 + margin;
+    const double step = P.cam[19];
+    const double E[3] = { P.cam[0], P.cam[1], P.cam[2] }, UL[3] = { P.cam[8], P.cam[9], P.cam[10] };
+    const double up[3] = { P.cam[12], P.cam[13], P.cam[14] }, right[3] = { P.cam[16], P.cam[17], P.cam[18] };
+    double a[4][3];                                                // eye -> corners, around the rectangle
+    const double cx[4] = { x0, x1, x1, x0 }, cy[4] = { y0, y0, y1, y1 };
+    double f_min = 1e300, mag = 1.0;
+    for (int k = 0; k < 4; ++k) {
+        double l2 = 0.0;
+        for (int c = 0; c < 3; ++c) {
+            const double pnt = UL[c] + step * cx[k] * right[c] - step * cy[k] * up[c];
+            a[k][c] = pnt - E[c];
+            l2 += a[k][c] * a[k][c];
+            mag = fmax(mag, fmax(fabs(pnt), fabs(E[c])));
+        }
+        f_min = fmin(f_min, sqrt(l2));
+    }
+    const double mid[3] = { 0.25 * (a[0][0] + a[1][0] + a[2][0] + a[3][0]), 0.25 * (a[0][1] + a[1][1] + a[2][1] + a[3][1]),
+                            0.25 * (a[0][2] + a[1][2] + a[2][2] + a[3][2]) };
+    double nrm[4][3];
+    bool planes_ok = true;
+    for (int k = 0; k < 4; ++k) {
+        const double* u = a[k]; const double* v = a[(k + 1) & 3];
+        double n[3] = { u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0] };
+        const double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        const double side = n[0] * mid[0] + n[1] * mid[1] + n[2] * mid[2];
+        if (!(len > 0.0) || !(fabs(side) > 0.0) || !(len < 1e300)) planes_ok = false;
+        const double sc = (side < 0.0 ? -1.0 : 1.0) / len;
+        for (int c = 0; c < 3; ++c) nrm[k][c] = n[c] * sc;         // unit, pointing into the pyramid
+    }
+    if (!planes_ok || !(f_min > 0.0)) return;                      // a degenerate camera: no lists
+    // what the tracer's rounding can turn a ray by, as an angle seen from the eye
+    const double angle = 1e-5 + 64.0 * 0x1p-24 * mag / f_min;
+    // -> does the ball {c, R} (or, with h, the box c +- h) reach into the pyramid?
+    auto reaches = [&](const double c[3], double R, const double* h, double extra) -> bool {
+        const double rel[3] = { c[0] - E[0], c[1] - E[1], c[2] - E[2] };
+        // the farthest point of the bound from the eye: a ray turned by `angle` is off by angle * distance there
+        const double dist = sqrt(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]) + R + (h ? sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]) : 0.0);
+        const double slack = angle * dist + 1e-6 * mag + extra;
+        bool in = true;
+        for (int k = 0; k < 4; ++k) {
+            double s = nrm[k][0] * rel[0] + nrm[k][1] * rel[1] + nrm[k][2] * rel[2] + R;
+            if (h) s += fabs(nrm[k][0]) * h[0] + fabs(nrm[k][1]) * h[1] + fabs(nrm[k][2]) * h[2];
+            in = in && (s >= -slack);                              // a NaN (a never-hit padding node) is out
+        }
+        return in;
+    };
+    uint32_t sph_mask = 0u, box_mask = 0u;
+    for (uint32_t i = 0; i < L.n_sph; ++i) {
+        const float4 sp = blob[L.sph_off + i];
+        const double c[3] = { sp.x, sp.y, sp.z }, R = sqrt((double)sp.w);
+        const double d2 = (c[0] - E[0]) * (c[0] - E[0]) + (c[1] - E[1]) * (c[1] - E[1]) + (c[2] - E[2]) * (c[2] - E[2]);
+        const double far2 = d2 + f_min * f_min + R * R;
+        // a sphere of radius zero or with a NaN in it: keep it a candidate (its test decides)
+        const bool sane = R > 0.0 && far2 < 1e300;
+        if (!sane || reaches(c, R, nullptr, 0x1p-20 * far2 / R)) sph_mask |= 1u << i;
+    }
+    for (uint32_t i = 0; i < L.n_box; ++i) {
+        const float4 bc = blob[L.box_off + 3u * i], bh = blob[L.box_off + 3u * i + 2u];
+        const double c[3] = { bc.x, bc.y, bc.z }, h[3] = { bh.x, bh.y, bh.z };
+        const bool sane = h[0] == h[0] && h[1] == h[1] && h[2] == h[2] && c[0] == c[0] && c[1] == c[1] && c[2] == c[2];
+        if (!sane || reaches(c, 0.0, h, 0.0)) box_mask |= 1u << i;
+    }
+    uint32_t n_leaf = 0u;
+    bool overflow = false;
+    auto node_reaches = [&](uint32_t level, uint32_t i) -> bool {
+        const float4 nb = blob[L.node_off[level] + i];
+        const double c[3] = { nb.x, nb.y, nb.z };
+        if (!(nb.w < 3e38f)) return nb.w == nb.w;                  // an unbounded node (a degenerate triangle) is always entered
+        return reaches(c, (double)nb.w, nullptr, 0.0);
+    };
+    if (L.n_tris != 0u) {
+        for (uint32_t i3 = 0; i3 < L.node_n[3]; ++i3) {
+            if (!node_reaches(3u, i3)) continue;
+            const uint32_t e2 = min(TREE_FAN * i3 + TREE_FAN, L.node_n[2]);
+            for (uint32_t i2 = TREE_FAN * i3; i2 < e2; ++i2) {
+                if (!node_reaches(2u, i2)) continue;
+                const uint32_t e1 = min(TREE_FAN * i2 + TREE_FAN, L.node_n[1]);
+                for (uint32_t i1 = TREE_FAN * i2; i1 < e1; ++i1) {
+                    if (!node_reaches(1u, i1)) continue;
+                    const uint32_t e0 = min(TREE_FAN * i1 + TREE_FAN, L.node_n[0]);
+                    for (uint32_t i0 = TREE_FAN * i1; i0 < e0; ++i0) {
+                        if (!node_reaches(0u, i0)) continue;
+                        if (n_leaf < TLIST_MAX_LEAVES) rec[3u + n_leaf++] = i0; else overflow = true;
+                    }
+                }
+            }
+        }
+    }
+    rec[0] = sph_mask; rec[1] = box_mask;
+    rec[2] = overflow ? TLIST_NONE : n_leaf;
+}
+
 // TRACE launches first mark every entry "path already over".
 __global__ void trace_fill_kernel(int32_t* hit, uint32_t* mat, size_t n)
 {
@@ -1449,16 +1695,7 @@ __global__ void resolve_kernel(const uint32_t* __restrict__ accum, float* __rest
     uint32_t y = blockIdx.y;
     if (x >= width || y >= height) return;
     uint4 a = *reinterpret_cast<const uint4*>(accum + 4u * ((size_t)y * width + x));
-    float4 v;
-    if (SEM == 0) {
-        float ns = (float)samples;
-        v.x = __uint_as_float(a.x) / ns; v.y = __uint_as_float(a.y) / ns; v.z = __uint_as_float(a.z) / ns;
-    } else {
-        float den = 255.0f * (float)samples;
-        v.x = (float)a.x / den; v.y = (float)a.y / den; v.z = (float)a.z / den;
-    }
-    if (gamma_sqrt) { v.x = __builtin_sqrtf(v.x); v.y = __builtin_sqrtf(v.y); v.z = __builtin_sqrtf(v.z); }
-    v.w = 1.0f;
+    const float4 v = resolve_pixel<SEM>(a.x, a.y, a.z, samples, gamma_sqrt != 0);
     uint32_t oy = flip_rows ? height - 1u - y : y;
     *reinterpret_cast<float4*>(out + 4u * ((size_t)oy * width + x)) = v;
 }
@@ -1527,10 +1764,18 @@ hipError_t scratch_for_device(int device, uint32_t** out)
 template <int SEM, int GEO, int MODE>
 static hipError_t launch_one(dim3 grid, size_t lds_bytes, hipStream_t stream, const TraceParams& P, const float4* blob,
                              uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm,
-                             const uint32_t* tile_order, uint32_t* tile_cost)
+                             const uint32_t* tile_order, uint32_t* tile_cost, const uint32_t* tile_lists)
 {
     hipLaunchKernelGGL((trace_kernel<SEM, GEO, MODE>), grid, dim3(64u * P.group_waves), lds_bytes, stream, P, blob, accum, st, th, tm,
-                       tile_order, tile_cost);
+                       tile_order, tile_cost, tile_lists);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_lists(hipStream_t stream, const TraceParams& P, const void* blob, uint32_t* lists)
+{
+    const uint32_t n_wt = 4u * P.tiles_x * P.tiles_y;
+    if (n_wt == 0u) return hipSuccess;
+    hipLaunchKernelGGL(tile_lists_kernel, dim3((n_wt + 63u) / 64u), dim3(64), 0, stream, P, static_cast<const float4*>(blob), lists);
     return hipGetLastError();
 }
 
@@ -1542,7 +1787,7 @@ hipError_t launch_tile_plan(hipStream_t stream, uint32_t* cost, uint32_t* work, 
 
 hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams& Pin, const void* blob,
                         uint32_t* accum, unsigned long long* st, int32_t* th, uint32_t* tm,
-                        const uint32_t* tile_order, uint32_t* tile_cost, uint32_t n_workgroups)
+                        const uint32_t* tile_order, uint32_t* tile_cost, uint32_t n_workgroups, const uint32_t* tile_lists)
 {
     const float4* b = static_cast<const float4*>(blob);
     const int tri_mode = Pin.scene.n_tris == 0 ? (Pin.scene.n_box != 0 ? 1 : 0) : (Pin.scene.tri_in_lds ? 1 : 2);
@@ -1552,13 +1797,19 @@ hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams
     const dim3 grid((4u * n_workgroups + P.group_waves - 1u) / P.group_waves);
     const size_t lds_bytes = ((size_t)P.scene.lds_words + (tri_mode ? lds_wave_words(P.group_waves, tri_mode == 2) : 0u)) * 16u;
     const int geo = tri_mode | (((sem == 0 && P.scene.n_cube != 0) || P.scene.has_glass || P.scene.tcol_off != 0 || (P.flags & 4u) != 0u) ? 4 : 0) |
-                    (P.rng_mode ? 8 : 0) | ((P.flags & RT_FLAG_LITERAL_GEOMETRY) != 0u ? 16 : 0);
-#define RT_CASE(S, G, M) if (sem == S && geo == G && mode == M) return launch_one<S, G, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm, tile_order, tile_cost)
+                    (P.rng_mode ? 8 : 0) | ((P.flags & RT_FLAG_LITERAL_GEOMETRY) != 0u ? 16 : 0) |
+                    ((RT_PSTEP != 0 && tile_lists != nullptr && P.rng_mode == 0 && (P.flags & RT_FLAG_LITERAL_GEOMETRY) == 0u && mode != 2) ? 32 : 0);
+    if ((geo & 32) == 0) tile_lists = nullptr;
+#define RT_CASE(S, G, M) if (sem == S && geo == G && mode == M) return launch_one<S, G, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm, tile_order, tile_cost, tile_lists)
 #define RT_CASES(S, G) RT_CASE(S, G, 0); RT_CASE(S, G, 1); RT_CASE(S, G, 2)
 #define RT_GEOS(S) RT_CASES(S, 0); RT_CASES(S, 1); RT_CASES(S, 2); RT_CASES(S, 4); RT_CASES(S, 5); RT_CASES(S, 6); \
                    RT_CASES(S, 8); RT_CASES(S, 9); RT_CASES(S, 10); RT_CASES(S, 12); RT_CASES(S, 13); RT_CASES(S, 14)
     RT_GEOS(0); RT_GEOS(1);
     RT_CASES(0, 16); RT_CASES(0, 20);                      // literal geometry: CPU rules, spheres and cubes, counter hash
+#define RT_PCASES(S, G) RT_CASE(S, G, 0); RT_CASE(S, G, 1)
+    RT_PCASES(0, 32); RT_PCASES(0, 33); RT_PCASES(0, 34); RT_PCASES(0, 36); RT_PCASES(0, 37); RT_PCASES(0, 38);   // primary steps: counter hash
+    RT_PCASES(1, 32); RT_PCASES(1, 33); RT_PCASES(1, 34); RT_PCASES(1, 36); RT_PCASES(1, 37); RT_PCASES(1, 38);
+#undef RT_PCASES
 #undef RT_GEOS
 #undef RT_CASES
 #undef RT_CASE

@@ -358,6 +358,16 @@ class RayTracingComputeShader:
         self._check(lib.rt_reset_accum(self._ctx))
         self.frame = 0
 
+    def discardAccum(self):
+        """rt_reset_accum for a caller that renders next: the next render call overwrites instead of adding (no clear)."""
+        self._check(lib.rt_discard_accum(self._ctx))
+        self.frame = 0
+
+    def renderResolved(self, width, height, spp, max_depth, seed, device_ptr, first_sample=0, grid_n=0, gamma_sqrt=False, flip_rows=True):
+        """rt_render + rt_resolve_device as one call (the resolve rides on the launch that ends the frame where it can)."""
+        self._check(lib.rt_render_resolved(self._ctx, width, height, spp, max_depth, seed, first_sample, grid_n,
+                                           C.c_void_p(device_ptr), int(gamma_sqrt), int(flip_rows)))
+
     def setAccumSamples(self, n):
         self._check(lib.rt_set_accum_samples(self._ctx, n))
 

@@ -22,6 +22,8 @@ tot = t.sum(axis=0) * 16
 names = ["sphere scan", "boxes / cubes", "triangle tree", "surface, draws, new direction"]
 if os.environ.get("PHASE_SPLIT") == "3":        # -DRT_PHASE_CLOCKS=3
     names = ["everything but the triangle tree", "walk by the whole wave, queueing", "passes over queued nodes", "passes over queued leaves"]
+if os.environ.get("PHASE_SPLIT") == "4":        # -DRT_PHASE_CLOCKS=4
+    names = ["primary steps", "other steps: closest hit", "other steps: surface, draws, direction", "(number of primary steps x 16)"]
 if os.environ.get("PHASE_SPLIT") == "2":        # the library was built with -DRT_PHASE_CLOCKS=2
     names = ["closest hit (all of it)", "record, normal", "accumulate, draws, scatter / restart", "new direction"]
 wi = max(1, st.wave_iterations)
@@ -29,4 +31,8 @@ print(f"{name}: {st.wave_iterations} wave iterations, lane use {st.segments / (6
 for n, v in zip(names, tot):
     print(f"  {n:32s} {100.0 * v / tot.sum():5.1f} %   {v / wi:8.0f} clocks per wave iteration")
 print(f"  {'all':32s} {tot.sum() / wi:8.0f} clocks per wave iteration")
+if os.environ.get("PHASE_SPLIT") == "4":
+    n_p = tot[3] / 256.0
+    print(f"  primary steps: {n_p:.0f} = {n_p / wi:.3f} of the steps, {tot[0] / max(1.0, n_p):.0f} clocks each; other steps: {(tot[1] + tot[2]) / max(1.0, wi - n_p):.0f} clocks each "
+          f"({tot[1] / max(1.0, wi - n_p):.0f} closest hit)")
 rt.close()
