@@ -96,6 +96,13 @@ struct rt_ctx {
     bool lists_valid = false;
     ListKey lists_key{};
     uint32_t scene_version = 0;          // counts the builds of the device copy of the scene
+    // Whether the lists pay: the kernels that use them count their waves' steps and primary steps (two sums in device
+    // memory that only grow); a copy comes back to pinned host memory whenever a plan is renewed, and a view of
+    // which fewer than LISTS_MIN_SHARE of the steps were primary (long paths: an enclosed scene) goes on without lists.
+    unsigned long long* d_step_counts = nullptr;
+    unsigned long long* h_step_counts = nullptr;     // pinned: {steps, primary steps} as last copied
+    unsigned long long seen_steps = 0, seen_psteps = 0;
+    bool lists_useless = false;
 
     int compute_units = 0;
     uint32_t lds_limit = rtd::LDS_WORKGROUP_MAX_BYTES;   // what a workgroup can have of a CU's LDS on this device (hipDeviceProp_t::sharedMemPerBlock, at most 160 KiB)
@@ -587,6 +594,8 @@ void rt_destroy(rt_ctx* ctx)
     (void)hipFree(ctx->d_tile_cost);
     (void)hipFree(ctx->d_tile_order);
     (void)hipFree(ctx->d_tile_lists);
+    (void)hipFree(ctx->d_step_counts);
+    (void)hipHostFree(ctx->h_step_counts);
     (void)hipFree(ctx->d_stage);
     delete ctx;
 }
@@ -798,13 +807,21 @@ static int make_plan(rt_ctx* ctx, uint32_t* cost, uint32_t* order, uint32_t n_ti
     return RT_OK;
 }
 
+// Primary steps trade steps for work: a wave takes more, cheaper steps.  That pays while the machine is kept full; a
+// launch of a few samples per pixel is over before it is (measured on 512 x 512, 16 samples: 58 us without the
+// lists, 77 us with them), so such a launch traces without them.
+constexpr uint32_t LISTS_MIN_SPP = 32u;
+// ... and while a fair share of a wave's steps are primary steps: where paths are long (an enclosed scene: one camera
+// ray for fourteen segments) the steps' bookkeeping costs more than the few primary steps save (measured: 1.2 %).
+constexpr double LISTS_MIN_SHARE = 0.10;
 // The candidate lists of the camera rays for this launch's tiling (nullptr: the scene has no use for them, or they are
 // switched off): made when the scene, the camera, the frame size or the row shard changed since they were last made.
 static int ensure_lists(rt_ctx* ctx, const rtd::TraceParams& P, const uint32_t** out)
 {
     *out = nullptr;
-    // (the masks of a list hold 32 spheres and 32 boxes: a scene beyond them has no lists)
-    if (ctx->env_no_tile_lists || P.rng_mode != 0 || (P.flags & RT_FLAG_LITERAL_GEOMETRY) != 0u || P.scene.n_sph > 32u || P.scene.n_box > 32u ||
+    // (the masks of a list hold 128 spheres and 32 boxes: a scene beyond them has no lists)
+    if (ctx->env_no_tile_lists || P.rng_mode != 0 || (P.flags & RT_FLAG_LITERAL_GEOMETRY) != 0u ||
+        P.scene.n_sph > rtd::TLIST_MAX_SPHERES || P.scene.n_box > rtd::TLIST_MAX_BOXES ||
         (P.scene.n_sph < 2u && P.scene.n_box == 0 && P.scene.n_tris == 0)) return RT_OK;
     rt_ctx::ListKey key{};
     memcpy(key.cam, P.cam, sizeof key.cam);
@@ -818,20 +835,29 @@ static int ensure_lists(rt_ctx* ctx, const rtd::TraceParams& P, const uint32_t**
         RT_HIP(ctx, hipMalloc(&ctx->d_tile_lists, sizeof(uint32_t) * rtd::TLIST_WORDS * (size_t)n_wt));
         ctx->lists_cap = n_wt;
     }
+    if (!ctx->d_step_counts) {
+        RT_HIP(ctx, hipMalloc(&ctx->d_step_counts, 2 * sizeof(unsigned long long)));
+        RT_HIP(ctx, hipMemsetAsync(ctx->d_step_counts, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        RT_HIP(ctx, hipHostMalloc(&ctx->h_step_counts, 2 * sizeof(unsigned long long)));
+        ctx->h_step_counts[0] = ctx->h_step_counts[1] = 0;
+    }
+    // what the counts say that came back since the last look (they may be a call or two old: this only steers speed)
+    const unsigned long long steps = ctx->h_step_counts[0], psteps = ctx->h_step_counts[1];
+    if (steps > ctx->seen_steps && psteps >= ctx->seen_psteps) {
+        ctx->lists_useless = (double)(psteps - ctx->seen_psteps) < LISTS_MIN_SHARE * (double)(steps - ctx->seen_steps);
+        ctx->seen_steps = steps; ctx->seen_psteps = psteps;
+    }
     if (!ctx->lists_valid || memcmp(&key, &ctx->lists_key, sizeof key) != 0) {
         RT_HIP(ctx, rtd::launch_tile_lists(ctx->stream, P, ctx->d_blob, ctx->d_tile_lists));
         ctx->lists_key = key; ctx->lists_valid = true;
+        ctx->lists_useless = false;                        // a new view: to be found out again
     }
-    *out = ctx->d_tile_lists;
+    if (!ctx->lists_useless) *out = ctx->d_tile_lists;
     return RT_OK;
 }
 
 // A render call of at least this many samples per pixel that has no plan yet traces its first PROBE_SPP samples in
 // the built-in order, makes the plan from what the tiles cost there, and traces the rest by that plan.
-// Primary steps trade steps for work: a wave takes more, cheaper steps.  That pays while the machine is kept full; a
-// launch of a few samples per pixel is over before it is (measured on 512 x 512, 16 samples: 58 us without the
-// lists, 77 us with them), so such a launch traces without them.
-constexpr uint32_t LISTS_MIN_SPP = 32u;
 constexpr uint32_t PROBE_MIN_SPP = 64u, PROBE_SPP = 8u;      // measured: 16 -> 8 takes the cold frame of the mesh scene from 17.0 to 16.4 ms, of the 4 968-triangle mesh from 31.5 to 26.7
 
 // Traces samples [P.first_sample, P.first_sample + P.spp) into `accum`: one launch by the plan in `order` (have_plan),
@@ -935,12 +961,15 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         const uint32_t* lists = nullptr;
         rc = ensure_lists(ctx, P, &lists);
         if (rc) { if (d_timeline) (void)hipFree(d_timeline); return rc; }
+        P.step_counts = lists ? ctx->d_step_counts : nullptr;
         const bool will_probe = !have_plan && !timeline_host && !ctx->env_no_probe && !ctx->env_no_tile_order && spp >= PROBE_MIN_SPP;
         rc = trace_frame(ctx, P, accum_ptr(ctx), stats ? 1 : 0, replan ? ctx->d_tile_cost : nullptr, ctx->d_tile_order, have_plan,
                          !timeline_host && !ctx->env_no_probe && !ctx->env_no_tile_order, replan, &plan_units, d_timeline, lists);
         // resolved by the launch itself unless a probe's plan may have cut tiles (trace_frame then dropped the request)
         resolved_in_launch = P.resolve_out != nullptr && !(will_probe && slices_allowed(ctx, spp - (ctx->probe_spp ? ctx->probe_spp : PROBE_SPP)) > 1u);
         if (replan) { ctx->plan_view = view; ctx->plan_age = 0; } else ++ctx->plan_age;
+        if (replan && lists && rc == RT_OK)
+            (void)hipMemcpyAsync(ctx->h_step_counts, ctx->d_step_counts, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
         if (rc) { if (d_timeline) (void)hipFree(d_timeline); return rc; }
         hipError_t le = hipSuccess;
         if (d_timeline) {

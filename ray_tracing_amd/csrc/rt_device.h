@@ -94,6 +94,9 @@ struct TraceParams {
     // writes its pixel's mean as resolve_kernel would.  resolve_out = nullptr: no resolve.
     uint32_t resolve_samples, resolve_gamma, resolve_flip;
     float*   resolve_out;
+    // Instances with primary steps add their waves' steps and primary steps here (two 64-bit sums that only grow):
+    // the host reads them now and then and stops handing out lists to a view whose steps are hardly ever primary.
+    unsigned long long* step_counts;
     SceneLayout scene;
 };
 
@@ -104,12 +107,14 @@ enum { ST_SAMPLES = 0, ST_SEGMENTS, ST_DIFFUSE, ST_SPECULAR, ST_TERMINAL, ST_TRI
 // Candidate lists of the camera rays, one record per 8x8-pixel wave tile (tile_lists_kernel makes them once per scene,
 // camera and frame size; trace_kernel's "primary steps" read them): every primitive that a camera ray through the
 // tile could be accepted by — conservatively: whatever touches the pyramid from the eye through the tile.
-//   word 0: spheres, bit s = sphere s in upload order among the spheres (scenes of up to 32)
-//   word 1: boxes, bit b likewise (up to 32)
-//   word 2: number of tree leaves that follow, or TLIST_NONE: no list for this tile (more leaves than fit, or a scene
-//           beyond the masks) — its waves then trace camera rays like any others
-//   word 3..: the leaves
-constexpr uint32_t TLIST_WORDS = 32u, TLIST_MAX_LEAVES = TLIST_WORDS - 3u, TLIST_NONE = 0xffffffffu;
+//   word 0: number of tree leaves listed at the record's end, or TLIST_NONE: no list for this tile (more leaves than
+//           fit) — its waves then trace camera rays like any others
+//   word 1: boxes, bit b = box b in upload order among the boxes (scenes of up to 32)
+//   word 2..5: spheres, bit s of the 128 = sphere s in upload order among the spheres
+//   word 6..: the leaves
+// A scene with more spheres or boxes than the masks hold has no lists.
+constexpr uint32_t TLIST_WORDS = 32u, TLIST_SPH_WORDS = 4u, TLIST_LEAF0 = 2u + TLIST_SPH_WORDS, TLIST_MAX_LEAVES = TLIST_WORDS - TLIST_LEAF0,
+                   TLIST_NONE = 0xffffffffu, TLIST_MAX_SPHERES = 32u * TLIST_SPH_WORDS, TLIST_MAX_BOXES = 32u;
 // A wave takes a primary step — only its lanes that are about to trace a camera ray take part, and they test the
 // tile's candidates instead of walking the scene — when all its live lanes are such, or at least this many.
 #ifndef RT_PSTEP_MIN

@@ -828,14 +828,17 @@ void trace_kernel(const TraceParams P,
     // alone (the others wait one step): they test the tile's candidates directly, no bounds, no queues.  The
     // candidates include every primitive whose test could accept such a ray, the closest hit is the same minimum
     // of (distance, index): the same words.  A step with fewer camera rays is an ordinary iteration for everyone.
-    uint32_t pl_sph = 0u, pl_box = 0u, pl_n = TLIST_NONE;
+    uint32_t pl_box = 0u, pl_n = TLIST_NONE;
+    const uint32_t* pl_sph = nullptr;                                 // TLIST_SPH_WORDS words
     const uint32_t* pl_leaves = nullptr;
     if (PSTEP && tile_lists) {
         const uint32_t wt = __builtin_amdgcn_readfirstlane((tile_y * 2u + (sub >> 1)) * (2u * P.tiles_x) + tile_x * 2u + (sub & 1u));
         const uint32_t* const rec_ = tile_lists + (size_t)wt * TLIST_WORDS;
-        pl_sph = rec_[0]; pl_box = rec_[1]; pl_n = rec_[2]; pl_leaves = rec_ + 3;
+        pl_n = rec_[0]; pl_box = rec_[1]; pl_sph = rec_ + 2; pl_leaves = rec_ + TLIST_LEAF0;
     }
+    const uint32_t pl_sph_words = (L.n_sph + 31u) >> 5;               // mask words in use
     const bool have_list = PSTEP && pl_n != TLIST_NONE;
+    uint32_t my_steps = 0u;                                           // of this lane's time in the loop: steps | primary steps << 16 (a wave's steps stay far below 65 536; beyond, the counts are off, which only blurs a heuristic)
 #if RT_PHASE_CLOCKS
     uint32_t phase_clk[4] = { 0u, 0u, 0u, 0u }, phase_t = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
@@ -847,6 +850,7 @@ void trace_kernel(const TraceParams P,
             const uint32_t n_all = (uint32_t)__popcll(__ballot(1)), n_first = (uint32_t)__popcll(__ballot(bounce == 0u));
             pstep = n_first == n_all || n_first >= PSTEP_MIN;
         }
+        if (PSTEP) my_steps += pstep ? 0x10001u : 1u;
         if (!pstep || bounce == 0u) {
         if (STATS && pstep && lane_is_first()) ++n_psteps;
         // ---- closest hit: Scene::hit (scene.h:232-255) /
@@ -892,10 +896,12 @@ void trace_kernel(const TraceParams P,
         }
         if (PSTEP && pstep) {
             // the tile's candidate spheres, in upload order (a later one replaces the best only by a strictly smaller key)
-            for (uint32_t m = pl_sph; m != 0u; m &= m - 1u) {
-                const uint32_t i = (uint32_t)__builtin_ctz(m);
-                test_sphere<SEM>(sph[i], reinterpret_cast<const uint32_t*>(sid)[i], o, d, best);
-                if (STATS) ++n_sph_test;
+            for (uint32_t w = 0; w < pl_sph_words; ++w) {
+                for (uint32_t m = pl_sph[w]; m != 0u; m &= m - 1u) {
+                    const uint32_t i = 32u * w + (uint32_t)__builtin_ctz(m);
+                    test_sphere<SEM>(sph[i], reinterpret_cast<const uint32_t*>(sid)[i], o, d, best);
+                    if (STATS) ++n_sph_test;
+                }
             }
         }
         for (uint32_t c = 0; !LIT && !(PSTEP && pstep) && c < n_chunks; ++c) {
@@ -1418,6 +1424,16 @@ void trace_kernel(const TraceParams P,
             }
         }
     }
+    if (PSTEP && !TRACE && P.step_counts != nullptr) {
+        // the wave's counts are those of its longest-lived lane
+        uint32_t st_ = my_steps;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t os = (uint32_t)__shfl_down(st_, off, 64);
+            st_ = (os & 0xffffu) > (st_ & 0xffffu) ? os : st_;
+        }
+        if (lane == 0u && st_ != 0u) { atomicAdd(&P.step_counts[0], (unsigned long long)(st_ & 0xffffu)); atomicAdd(&P.step_counts[1], (unsigned long long)(st_ >> 16)); }
+    }
     // What this tile cost, for the next frame's launch order: the longest of its four waves' loops.
     if (!TRACE && tile_cost && lane == 0u)
         atomicMax(&tile_cost[tile], (COST_CLOCK ? (uint32_t)((__builtin_amdgcn_s_memtime() - c_start) >> 8) + 1u : iterations) * n_slices);
@@ -1575,10 +1591,11 @@ void tile_lists_kernel(const TraceParams P, const float4* __restrict__ blob, uin
         gy_lo = min(gy_lo, gy); gy_hi = max(gy_hi, gy);
     }
     const uint32_t gx_lo = wtx * 8u;
-    rec[0] = 0u; rec[1] = 0u; rec[2] = TLIST_NONE;
+    rec[0] = TLIST_NONE; rec[1] = 0u;
+    for (uint32_t w = 0; w < TLIST_SPH_WORDS; ++w) rec[2u + w] = 0u;
     if (gy_lo > gy_hi || gx_lo >= P.width) return;                 // no pixel: no wave reads this record
     const SceneLayout& L = P.scene;
-    if (L.n_sph > 32u || L.n_box > 32u) return;                    // beyond the masks: no lists for this scene
+    if (L.n_sph > TLIST_MAX_SPHERES || L.n_box > TLIST_MAX_BOXES) return;   // beyond the masks: no lists for this scene
 
     // the tile's rectangle in pixel units, a little wider than its pixels; the grid as written lets the x offset
     // accumulate beyond the pixel (rayTracer.h:98-99): by less than grid_n / 2 pixels
@@ -1631,7 +1648,8 @@ void tile_lists_kernel(const TraceParams P, const float4* __restrict__ blob, uin
         }
         return in;
     };
-    uint32_t sph_mask = 0u, box_mask = 0u;
+    uint32_t sph_mask[TLIST_SPH_WORDS] = { 0u, 0u, 0u, 0u }, box_mask = 0u;
+    static_assert(TLIST_SPH_WORDS == 4u, "initialiser above");
     for (uint32_t i = 0; i < L.n_sph; ++i) {
         const float4 sp = blob[L.sph_off + i];
         const double c[3] = { sp.x, sp.y, sp.z }, R = sqrt((double)sp.w);
@@ -1639,7 +1657,7 @@ void tile_lists_kernel(const TraceParams P, const float4* __restrict__ blob, uin
         const double far2 = d2 + f_min * f_min + R * R;
         // a sphere of radius zero or with a NaN in it: keep it a candidate (its test decides)
         const bool sane = R > 0.0 && far2 < 1e300;
-        if (!sane || reaches(c, R, nullptr, 0x1p-20 * far2 / R)) sph_mask |= 1u << i;
+        if (!sane || reaches(c, R, nullptr, 0x1p-20 * far2 / R)) sph_mask[i >> 5] |= 1u << (i & 31u);
     }
     for (uint32_t i = 0; i < L.n_box; ++i) {
         const float4 bc = blob[L.box_off + 3u * i], bh = blob[L.box_off + 3u * i + 2u];
@@ -1667,14 +1685,15 @@ void tile_lists_kernel(const TraceParams P, const float4* __restrict__ blob, uin
                     const uint32_t e0 = min(TREE_FAN * i1 + TREE_FAN, L.node_n[0]);
                     for (uint32_t i0 = TREE_FAN * i1; i0 < e0; ++i0) {
                         if (!node_reaches(0u, i0)) continue;
-                        if (n_leaf < TLIST_MAX_LEAVES) rec[3u + n_leaf++] = i0; else overflow = true;
+                        if (n_leaf < TLIST_MAX_LEAVES) rec[TLIST_LEAF0 + n_leaf++] = i0; else overflow = true;
                     }
                 }
             }
         }
     }
-    rec[0] = sph_mask; rec[1] = box_mask;
-    rec[2] = overflow ? TLIST_NONE : n_leaf;
+    rec[1] = box_mask;
+    for (uint32_t w = 0; w < TLIST_SPH_WORDS; ++w) rec[2u + w] = sph_mask[w];
+    rec[0] = overflow ? TLIST_NONE : n_leaf;
 }
 
 // TRACE launches first mark every entry "path already over".
