@@ -115,6 +115,7 @@ struct rt_ctx {
     uint32_t group_waves = 4;           // waves per workgroup (RT_GROUP_WAVES: 1 .. 8, for measurements)
     bool env_no_tile_order = false, env_no_slices = false, env_mesh_in_lds = false, env_no_probe = false, env_no_tile_lists = false;
     uint32_t env_leaf = 0;               // RT_LEAF: triangles per tree leaf for every mesh (measurements); 0: chosen by mesh size
+    uint32_t env_tree_levels = 0;        // RT_TREE_LEVELS: at most this many tree levels, 4 .. 8 (measurements); 0: as many as the mesh needs
     float slice_share = 0.25f, slice_early = 0.5f;       // RT_SLICE_SHARE, RT_SLICE_EARLY (measurements)
     uint32_t slice_min_spp = 16u, slice_max = 16u;       // RT_SLICE_MIN_SPP, RT_SLICE_MAX
     uint32_t probe_spp = 0u;                             // RT_PROBE_SPP (0: the built-in PROBE_SPP)
@@ -275,7 +276,7 @@ static void build_tree(const std::vector<rt_triangle>& tris, const rtd::SceneLay
     }
     // Level l node i covers the sorted triangles [span*i, span*(i+1)), span = LEAF * FAN^l.
     uint32_t span = leaf;
-    for (uint32_t l = 0; l < rtd::TREE_LEVELS; ++l, span *= rtd::TREE_FAN) {
+    for (uint32_t l = 0; l < L.tree_levels; ++l, span *= rtd::TREE_FAN) {
         for (uint32_t i = 0; i < node_pad[l]; ++i) {
             Word& w = blob[L.node_off[l] + i];
             w.f[0] = w.f[1] = w.f[2] = nan; w.f[3] = 0.0f;
@@ -342,7 +343,7 @@ static void build_tree(const std::vector<rt_triangle>& tris, const rtd::SceneLay
 
 // Where everything goes in the blob (layout: rt_device.h) for the arrays uploaded so far; fails when the part that
 // must be staged does not fit.  Cheap: run at every upload, so that a scene that cannot be rendered is refused there.
-struct BlobPlan { rtd::SceneLayout L; uint32_t node_pad[rtd::TREE_LEVELS]; uint32_t n_tri_pad, n_sph, n_box, n_cube; bool colors; };
+struct BlobPlan { rtd::SceneLayout L; uint32_t node_pad[rtd::MAX_TREE_LEVELS]; uint32_t n_tri_pad, n_sph, n_box, n_cube; bool colors; };
 static int plan_blob(rt_ctx* ctx, BlobPlan& B)
 {
     const uint32_t n_shapes = (uint32_t)ctx->shapes.size(), n_tris = (uint32_t)ctx->tris.size();
@@ -366,16 +367,22 @@ static int plan_blob(rt_ctx* ctx, BlobPlan& B)
     const uint32_t n_tri_pad = (n_tris + leaf - 1u) / leaf * leaf;
     {
         uint32_t n = n_tri_pad / leaf;
-        for (uint32_t l = 0; l < rtd::TREE_LEVELS; ++l) {
+        // Four levels at least (the walk's); more while the top one has too many nodes to scan (rt_device.h).
+        L.tree_levels = 0;
+        for (uint32_t l = 0; l < rtd::MAX_TREE_LEVELS; ++l) {
             L.node_n[l] = n;
             B.node_pad[l] = (n + rtd::TREE_FAN - 1u) / rtd::TREE_FAN * rtd::TREE_FAN;
+            L.tree_levels = l + 1u;
+            if (l + 1u >= rtd::TREE_LEVELS && n <= rtd::TREE_TOP_MAX) break;
             n = (n + rtd::TREE_FAN - 1u) / rtd::TREE_FAN;
         }
+        if (ctx->env_tree_levels) L.tree_levels = std::min(L.tree_levels, std::max(rtd::TREE_LEVELS, ctx->env_tree_levels));   // measurements
+        if (ctx->cfg.rng != RT_RNG_HASH) L.tree_levels = rtd::TREE_LEVELS;      // the kernels of the shader's own stream walk four levels (the top one then is as long as it is)
         // The top level is scanned linearly, so it is not grouped any further.
     }
     L.cub_off = L.box_off + 3u * n_box;
     uint32_t off = L.cub_off + 4u * n_cube;
-    for (int l = (int)rtd::TREE_LEVELS - 1; l >= 0; --l) { L.node_off[l] = off; off += B.node_pad[l]; }
+    for (int l = (int)L.tree_levels - 1; l >= 0; --l) { L.node_off[l] = off; off += B.node_pad[l]; }
     L.tri_off = off;
     const uint32_t staged_words = L.tri_off + 4u * n_tri_pad;        // what a workgroup stages when the mesh fits
     // The place of each uploaded triangle in the sorted list is looked up once per hit: it stays in global memory.
@@ -385,10 +392,10 @@ static int plan_blob(rt_ctx* ctx, BlobPlan& B)
         return fail(ctx, RT_ERR_INVALID_ARG, "scene: RT_FLAG_LITERAL_GEOMETRY renders spheres and Cubes only (%u boxes, %u triangles uploaded)", n_box, n_tris);
     B.colors = !ctx->tri_colors.empty() && ctx->tri_colors.size() == 3u * (size_t)n_tris;
     const uint32_t wave_words = (n_tris || n_box) ? rtd::lds_wave_words(ctx->group_waves, false) : 0u;     // queues and slots of the spread tests
-    if ((size_t)(L.node_off[rtd::TREE_LEVELS - 1u] + (n_tris ? rtd::lds_wave_words(ctx->group_waves, true) : wave_words)) * 16u > ctx->lds_limit)
+    if ((size_t)(L.node_off[L.tree_levels - 1u] + (n_tris ? rtd::lds_wave_words(ctx->group_waves, true) : wave_words)) * 16u > ctx->lds_limit)
         return fail(ctx, RT_ERR_INVALID_ARG, "scene: %u shapes need more than the %u bytes of LDS a workgroup can have on this device", n_shapes, ctx->lds_limit);
-    if ((size_t)(staged_words + wave_words) * 16u <= std::min(rtd::LDS_MAX_BYTES, ctx->lds_limit) && ctx->env_mesh_in_lds) { L.lds_words = staged_words; L.tri_in_lds = 1; }
-    else { L.lds_words = L.node_off[rtd::TREE_LEVELS - 1u]; L.tri_in_lds = 0; }     // the mesh and its tree stay in global memory
+    if ((size_t)(staged_words + wave_words) * 16u <= std::min(rtd::LDS_MAX_BYTES, ctx->lds_limit) && ctx->env_mesh_in_lds && L.tree_levels == rtd::TREE_LEVELS) { L.lds_words = staged_words; L.tri_in_lds = 1; }
+    else { L.lds_words = L.node_off[L.tree_levels - 1u]; L.tri_in_lds = 0; }     // the mesh and its tree stay in global memory
     // Per-triangle albedo: read only at a hit, so it stays in global memory behind everything else.
     if (B.colors) { L.tcol_off = L.total_words; L.total_words += n_tris; }
     B.L = L; B.n_tri_pad = n_tri_pad; B.n_sph = n_sph; B.n_box = n_box; B.n_cube = n_cube;
@@ -572,6 +579,7 @@ int rt_create(rt_ctx** out, const rt_config* cfg)
     ctx->env_mesh_in_lds = env_on("RT_MESH_IN_LDS");
     if (const char* v = getenv("RT_LEAF")) { const int n = atoi(v); if (n >= 1 && n <= (int)rtd::TREE_LEAF && (n & (n - 1)) == 0) ctx->env_leaf = (uint32_t)n; }
     ctx->env_no_probe = env_on("RT_NO_PROBE");
+    if (const char* v = getenv("RT_TREE_LEVELS")) { const int n = atoi(v); if (n >= (int)rtd::TREE_LEVELS && n <= (int)rtd::MAX_TREE_LEVELS) ctx->env_tree_levels = (uint32_t)n; }
     ctx->env_no_tile_lists = env_on("RT_NO_TILE_LISTS");
     if (const char* v = getenv("RT_SLICE_SHARE")) { const float f = (float)atof(v); if (f > 0.0f) ctx->slice_share = f; }
     if (const char* v = getenv("RT_SLICE_EARLY")) { const float f = (float)atof(v); if (f > 0.0f) ctx->slice_early = f; }

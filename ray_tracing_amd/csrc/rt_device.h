@@ -52,15 +52,22 @@ namespace rtd {
 #ifndef RT_TREE_FAN
 #define RT_TREE_FAN 8
 #endif
-constexpr uint32_t TREE_LEAF = RT_TREE_LEAF, TREE_FAN = RT_TREE_FAN, TREE_LEVELS = 4;
+// The walk handles the four levels 0 .. 3 with its queues and stacks.  A mesh whose level 3 would have more than
+// TREE_TOP_MAX nodes (some 65 000 triangles and more) gets further levels on top, up to MAX_TREE_LEVELS in all, until the
+// top one is that short: the wave descends through those together, depth first, and enters the level-3 nodes that any
+// of its rays can touch (SceneLayout::tree_levels; 4 for every smaller mesh, whose upper levels may hold a single node).
+// (Measured with a sheet of 20 000 triangles, ten level-3 nodes: a fifth level costs 8 % — scanning ten nodes is
+// cheaper than the shared stack —; with 199 712 triangles, 98 level-3 nodes: two more levels save 11 %.)
+constexpr uint32_t TREE_LEAF = RT_TREE_LEAF, TREE_FAN = RT_TREE_FAN, TREE_LEVELS = 4, MAX_TREE_LEVELS = 8, TREE_TOP_MAX = 32;
 constexpr uint32_t SMALL_MESH_TRIS = 800u;
 constexpr uint32_t TREE_LEAF_SMALL = TREE_LEAF >= 2u ? TREE_LEAF / 2u : TREE_LEAF;
 static_assert((TREE_LEAF & (TREE_LEAF - 1u)) == 0u, "a leaf holds a power of two of triangles (lanes of a pass find theirs by shift and mask)");
 struct SceneLayout {
     uint32_t n_shapes, n_sph_pad, n_box, n_cube, n_tris;
     uint32_t rec_off, sph_off, sid_off, box_off, cub_off, inv_off, tri_off;   // in 16-byte words
-    uint32_t node_off[TREE_LEVELS];                         // level 0 .. 3
-    uint32_t node_n[TREE_LEVELS];                           // real (unpadded) node counts
+    uint32_t node_off[MAX_TREE_LEVELS];                     // level 0 .. tree_levels - 1
+    uint32_t node_n[MAX_TREE_LEVELS];                       // real (unpadded) node counts
+    uint32_t tree_levels;                                   // TREE_LEVELS .. MAX_TREE_LEVELS
     uint32_t total_words;                                   // whole blob
     uint32_t lds_words;                                     // prefix staged in LDS
     uint32_t tri_in_lds;                                    // 1 if the tree and tri are part of that prefix
@@ -168,7 +175,11 @@ static_assert(TREE_LEVELS == 4u, "stack entries carry two bits of level, the wal
 #endif
 constexpr uint32_t POOL_SUM_BYTES = RT_POOL ? 3u * 64u * 4u + 64u * 16u : 0u;
 constexpr uint32_t WAVE_LDS_WORDS = (QUEUE_ENTRIES * 4u + 64u * 8u + NODE_STACK_STAGED * 4u + POOL_SUM_BYTES) / 16u;
-constexpr uint32_t WAVE_LDS_WORDS_GLOBAL = (QUEUE_ENTRIES * 4u + 64u * 8u + NODE_STACK_GLOBAL * 4u + POOL_SUM_BYTES) / 16u;
+// ... and, for a mesh in global memory, the stack of (level, node) the wave shares while it descends through the levels
+// above the third together: depth first, at most TREE_FAN - 1 siblings waiting per level and the node in hand.
+constexpr uint32_t UPPER_STACK_ENTRIES = 32u;
+static_assert((MAX_TREE_LEVELS - TREE_LEVELS) * (TREE_FAN - 1u) + 1u <= UPPER_STACK_ENTRIES, "the shared stack of the upper levels overflows");
+constexpr uint32_t WAVE_LDS_WORDS_GLOBAL = (QUEUE_ENTRIES * 4u + 64u * 8u + NODE_STACK_GLOBAL * 4u + POOL_SUM_BYTES + UPPER_STACK_ENTRIES * 4u) / 16u;
 // The 16-byte words a workgroup of `group_waves` waves needs behind the staged scene.
 constexpr uint32_t lds_wave_words(uint32_t group_waves, bool mesh_in_global) { return group_waves * (mesh_in_global ? WAVE_LDS_WORDS_GLOBAL : WAVE_LDS_WORDS); }
 

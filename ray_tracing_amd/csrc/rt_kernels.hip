@@ -603,7 +603,8 @@ RT_DEV float4 resolve_pixel(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t samp
 // would cost: 12 % on the four-sphere scene); bit 3: draws come from the
 // shader's own random() instead of the counter hash; bit 4 (CPU rules, spheres and cubes only): the geometry in the
 // reference's literal arithmetic, see LIT below; bit 5 (counter hash, recipe arithmetic): camera rays are traced in
-// steps of their own from their tile's candidate list, see PSTEP below.  MODE 0: render.  MODE 1: render and count work.  MODE 2:
+// steps of their own from their tile's candidate list, see PSTEP below; bit 6 (a mesh in global memory, counter hash): the
+// mesh's tree has levels above the walk's four, see DEEP_TREE below.  MODE 0: render.  MODE 1: render and count work.  MODE 2:
 // follow one sample, record hit and material ids, leave the accumulator alone.
 //
 // One loop iteration = one ray segment of every live lane: closest hit, then
@@ -645,6 +646,9 @@ void trace_kernel(const TraceParams P,
     // pooled restart reads its pixel's coordinates from the pixel's home lane, which a primary step may have left out.
     // An instance of its own (GEO bit 5), launched when the scene has lists: the others keep their code as it was.
     constexpr bool PSTEP = (GEO & 32) != 0;
+    // A mesh (in global memory) whose tree has levels above the walk's four: an instance of its own as well (GEO bit 6).
+    constexpr bool DEEP_TREE = (GEO & 64) != 0;
+    static_assert(!DEEP_TREE || ((GEO & 3) == 2 && (GEO & 8) == 0), "upper tree levels: a mesh in global memory, counter hash");
     static_assert(!PSTEP || (!RNG_GLSL && (GEO & 16) == 0), "primary steps: counter hash, recipe arithmetic");
     extern __shared__ float4 lds[];
     const uint32_t tid = threadIdx.x;
@@ -1118,7 +1122,43 @@ void trace_kernel(const TraceParams P,
                 while (ns_len >= node_pass) bound_pass(node_pass);
                 return true;
             };
-            for (uint32_t i3 = 0; i3 < L.node_n[3]; ++i3) {
+            // The level-3 nodes to walk: all of them, one after the other — or, for a large mesh, which has levels above
+            // the third (rt_device.h), those that the wave reaches going down through these levels together, depth first: a
+            // node is entered when the ray of any live lane can touch it, and its children wait on a small stack the wave
+            // shares.
+            const uint32_t top = DEEP_TREE ? L.tree_levels - 1u : 3u;
+            uint32_t* const upper = queue + (WAVE_LDS_WORDS_GLOBAL * 4u - UPPER_STACK_ENTRIES);
+            uint32_t top_next = 0u, un = 0u;                       // wave-uniform
+            for (;;) {
+                uint32_t i3 = 0u;
+                if (top == 3u) {
+                    if (top_next >= L.node_n[3]) break;
+                    i3 = top_next++;
+                } else {
+                    bool got = false;
+                    for (;;) {
+                        if (un == 0u) {
+                            if (top_next >= L.node_n[top]) break;
+                            if (lane_is_first()) upper[0] = (top << 24) | top_next;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            ++top_next; un = 1u;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const uint32_t ent = __builtin_amdgcn_readfirstlane(upper[un - 1u]);
+                        --un;
+                        const uint32_t lvl = ent >> 24, node = ent & 0xffffffu;
+                        if (lvl == 3u) { i3 = node; got = true; break; }
+                        if (STATS) ++n_node;
+                        const bool touch_u = !cull || bound_hit<SEM>(nodes[L.node_off[lvl] + node], o, d, best.key);
+                        if (__ballot(touch_u) == 0ull) continue;
+                        const uint32_t c0 = TREE_FAN * node, c1 = min(c0 + TREE_FAN, L.node_n[lvl - 1u]);
+                        if (lane_is_first())
+                            for (uint32_t c = c0; c < c1; ++c) upper[un + (c1 - 1u - c)] = ((lvl - 1u) << 24) | c;   // the lowest child on top
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        un += c1 - c0;
+                    }
+                    if (!got) break;
+                }
                 if (STATS) ++n_node;
                 const bool touch3 = !cull || bound_hit<SEM>(node3[i3], o, d, best.key);
                 const unsigned long long touching3 = __ballot(touch3);
@@ -1674,20 +1714,21 @@ void tile_lists_kernel(const TraceParams P, const float4* __restrict__ blob, uin
         return reaches(c, (double)nb.w, nullptr, 0.0);
     };
     if (L.n_tris != 0u) {
-        for (uint32_t i3 = 0; i3 < L.node_n[3]; ++i3) {
-            if (!node_reaches(3u, i3)) continue;
-            const uint32_t e2 = min(TREE_FAN * i3 + TREE_FAN, L.node_n[2]);
-            for (uint32_t i2 = TREE_FAN * i3; i2 < e2; ++i2) {
-                if (!node_reaches(2u, i2)) continue;
-                const uint32_t e1 = min(TREE_FAN * i2 + TREE_FAN, L.node_n[1]);
-                for (uint32_t i1 = TREE_FAN * i2; i1 < e1; ++i1) {
-                    if (!node_reaches(1u, i1)) continue;
-                    const uint32_t e0 = min(TREE_FAN * i1 + TREE_FAN, L.node_n[0]);
-                    for (uint32_t i0 = TREE_FAN * i1; i0 < e0; ++i0) {
-                        if (!node_reaches(0u, i0)) continue;
-                        if (n_leaf < TLIST_MAX_LEAVES) rec[TLIST_LEAF0 + n_leaf++] = i0; else overflow = true;
-                    }
+        // depth first from every node of the top level; at most TREE_FAN - 1 siblings wait per level
+        uint32_t stack[MAX_TREE_LEVELS * TREE_FAN];
+        const uint32_t top = L.tree_levels - 1u;
+        for (uint32_t it = 0; it < L.node_n[top] && !overflow; ++it) {
+            uint32_t n = 0u;
+            stack[n++] = (top << 24) | it;
+            while (n != 0u && !overflow) {
+                const uint32_t ent = stack[--n], lvl = ent >> 24, node = ent & 0xffffffu;
+                if (!node_reaches(lvl, node)) continue;
+                if (lvl == 0u) {
+                    if (n_leaf < TLIST_MAX_LEAVES) rec[TLIST_LEAF0 + n_leaf++] = node; else overflow = true;
+                    continue;
                 }
+                const uint32_t c0 = TREE_FAN * node, c1 = min(c0 + TREE_FAN, L.node_n[lvl - 1u]);
+                for (uint32_t c = c1; c-- > c0;) stack[n++] = ((lvl - 1u) << 24) | c;      // the lowest child on top
             }
         }
     }
@@ -1819,7 +1860,8 @@ hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams
                     (P.rng_mode ? 8 : 0) | ((P.flags & RT_FLAG_LITERAL_GEOMETRY) != 0u ? 16 : 0) |
                     ((RT_PSTEP != 0 && tile_lists != nullptr && P.rng_mode == 0 && (P.flags & RT_FLAG_LITERAL_GEOMETRY) == 0u && mode != 2) ? 32 : 0);
     if ((geo & 32) == 0) tile_lists = nullptr;
-#define RT_CASE(S, G, M) if (sem == S && geo == G && mode == M) return launch_one<S, G, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm, tile_order, tile_cost, tile_lists)
+    const int deep = (tri_mode == 2 && P.scene.tree_levels > TREE_LEVELS) ? 64 : 0;          // (never with the shader's own stream: rt_api.cpp keeps such a tree at four levels)
+#define RT_CASE(S, G, M) if (sem == S && (geo | deep) == G && mode == M) return launch_one<S, G, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm, tile_order, tile_cost, tile_lists)
 #define RT_CASES(S, G) RT_CASE(S, G, 0); RT_CASE(S, G, 1); RT_CASE(S, G, 2)
 #define RT_GEOS(S) RT_CASES(S, 0); RT_CASES(S, 1); RT_CASES(S, 2); RT_CASES(S, 4); RT_CASES(S, 5); RT_CASES(S, 6); \
                    RT_CASES(S, 8); RT_CASES(S, 9); RT_CASES(S, 10); RT_CASES(S, 12); RT_CASES(S, 13); RT_CASES(S, 14)
@@ -1828,6 +1870,8 @@ hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams
 #define RT_PCASES(S, G) RT_CASE(S, G, 0); RT_CASE(S, G, 1)
     RT_PCASES(0, 32); RT_PCASES(0, 33); RT_PCASES(0, 34); RT_PCASES(0, 36); RT_PCASES(0, 37); RT_PCASES(0, 38);   // primary steps: counter hash
     RT_PCASES(1, 32); RT_PCASES(1, 33); RT_PCASES(1, 34); RT_PCASES(1, 36); RT_PCASES(1, 37); RT_PCASES(1, 38);
+    RT_CASES(0, 66); RT_CASES(0, 70); RT_PCASES(0, 98); RT_PCASES(0, 102);                 // ... and a tree of more than four levels
+    RT_CASES(1, 66); RT_CASES(1, 70); RT_PCASES(1, 98); RT_PCASES(1, 102);
 #undef RT_PCASES
 #undef RT_GEOS
 #undef RT_CASES

@@ -1,8 +1,10 @@
 """Does gloo complete two asynchronous all_reduce of device tensors that are in flight together?
-(Rehearsal aid for bench.py's N > 1 path on a one-GPU box; not part of the product.)"""
-import os, sys, time
+(Rehearsal aid for bench.py's N > 1 path on a one-GPU box; not part of the product.)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/gloo_two_in_flight.py"""
+import faulthandler, os, sys, time
 import torch, torch.distributed as dist
 rank = int(os.environ["RANK"])
+faulthandler.dump_traceback_later(45, exit=True)          # a stall ends here, with every thread's stack on stderr
 torch.cuda.set_device(0)
 dist.init_process_group("gloo")
 a = torch.full((1080, 1920, 4), rank + 1, dtype=torch.int32, device="cuda")
