@@ -115,6 +115,7 @@ struct rt_ctx {
     uint32_t group_waves = 4;           // waves per workgroup (RT_GROUP_WAVES: 1 .. 8, for measurements)
     bool env_no_tile_order = false, env_no_slices = false, env_mesh_in_lds = false, env_no_probe = false, env_no_tile_lists = false;
     uint32_t env_leaf = 0;               // RT_LEAF: triangles per tree leaf for every mesh (measurements); 0: chosen by mesh size
+    uint32_t lists_min_spp = 32u;        // RT_LISTS_MIN_SPP: launches of fewer samples per pixel trace without the camera rays' lists (measurements, tests)
     uint32_t env_tree_levels = 0;        // RT_TREE_LEVELS: at most this many tree levels, 4 .. 8 (measurements); 0: as many as the mesh needs
     float slice_share = 0.25f, slice_early = 0.5f;       // RT_SLICE_SHARE, RT_SLICE_EARLY (measurements)
     uint32_t slice_min_spp = 16u, slice_max = 16u;       // RT_SLICE_MIN_SPP, RT_SLICE_MAX
@@ -579,6 +580,7 @@ int rt_create(rt_ctx** out, const rt_config* cfg)
     ctx->env_mesh_in_lds = env_on("RT_MESH_IN_LDS");
     if (const char* v = getenv("RT_LEAF")) { const int n = atoi(v); if (n >= 1 && n <= (int)rtd::TREE_LEAF && (n & (n - 1)) == 0) ctx->env_leaf = (uint32_t)n; }
     ctx->env_no_probe = env_on("RT_NO_PROBE");
+    if (const char* v = getenv("RT_LISTS_MIN_SPP")) { const int n = atoi(v); if (n >= 1) ctx->lists_min_spp = (uint32_t)n; }
     if (const char* v = getenv("RT_TREE_LEVELS")) { const int n = atoi(v); if (n >= (int)rtd::TREE_LEVELS && n <= (int)rtd::MAX_TREE_LEVELS) ctx->env_tree_levels = (uint32_t)n; }
     ctx->env_no_tile_lists = env_on("RT_NO_TILE_LISTS");
     if (const char* v = getenv("RT_SLICE_SHARE")) { const float f = (float)atof(v); if (f > 0.0f) ctx->slice_share = f; }
@@ -818,7 +820,7 @@ static int make_plan(rt_ctx* ctx, uint32_t* cost, uint32_t* order, uint32_t n_ti
 // Primary steps trade steps for work: a wave takes more, cheaper steps.  That pays while the machine is kept full; a
 // launch of a few samples per pixel is over before it is (measured on 512 x 512, 16 samples: 58 us without the
 // lists, 77 us with them), so such a launch traces without them.
-constexpr uint32_t LISTS_MIN_SPP = 32u;
+// (rt_ctx::lists_min_spp = 32)
 // ... and while a fair share of a wave's steps are primary steps: where paths are long (an enclosed scene: one camera
 // ray for fourteen segments) the steps' bookkeeping costs more than the few primary steps save (measured: 1.2 %).
 constexpr double LISTS_MIN_SHARE = 0.10;
@@ -885,7 +887,7 @@ static int trace_frame(rt_ctx* ctx, rtd::TraceParams P, uint32_t* accum, int mod
         probe.resolve_out = nullptr;                       // the frame ends with the launch after this one
         P.overwrite = 0u;                                  // ... which adds to what this one stores
         RT_HIP(ctx, rtd::launch_trace((int)ctx->cfg.semantics, mode, ctx->stream, probe, ctx->d_blob, accum, ctx->d_stats, nullptr, nullptr,
-                                      nullptr, cost, n_tiles, probe_spp >= LISTS_MIN_SPP ? lists : nullptr));
+                                      nullptr, cost, n_tiles, probe_spp >= ctx->lists_min_spp ? lists : nullptr));
         P.first_sample += probe_spp; P.spp -= probe_spp;
         int rc = make_plan(ctx, cost, order, n_tiles, P.spp, plan_units);
         if (rc) return rc;
@@ -895,7 +897,7 @@ static int trace_frame(rt_ctx* ctx, rtd::TraceParams P, uint32_t* accum, int mod
         if (*plan_units != n_tiles) P.resolve_out = nullptr;
     }
     RT_HIP(ctx, rtd::launch_trace((int)ctx->cfg.semantics, mode, ctx->stream, P, ctx->d_blob, accum, ctx->d_stats, d_timeline, nullptr,
-                                  have_plan ? order : nullptr, cost, have_plan ? *plan_units : n_tiles, P.spp >= LISTS_MIN_SPP ? lists : nullptr));
+                                  have_plan ? order : nullptr, cost, have_plan ? *plan_units : n_tiles, P.spp >= ctx->lists_min_spp ? lists : nullptr));
     if (plan_after) return make_plan(ctx, cost, order, n_tiles, spp_all, plan_units);
     return RT_OK;
 }

@@ -254,6 +254,17 @@ def run_calls(seed):
         check(f"{shards} row shards of {band}-row bands")
         rt.renderNoAlloc(buf.data_ptr(), w, h, spp, depth, cfg.seed)
         check("the call that allocates nothing")
+        # a frame that starts from a discarded accumulator and ends with its resolve (rt_discard_accum, rt_render_resolved)
+        out = torch.full((h, w, 4), -1.0, dtype=torch.float32, device="cuda")
+        want = orc.resolve(acc, spp, cfg.semantics, gamma_sqrt=(cfg.semantics == 0))
+        for rep in range(2):
+            buf.fill_(987654321)
+            rt.discardAccum()
+            rt.renderResolved(w, h, spp, depth, cfg.seed, out.data_ptr(), gamma_sqrt=(cfg.semantics == 0))
+            torch.cuda.synchronize()
+            if not np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)):
+                problems.append(f"discard + render_resolved, call {rep}: the resolved frame differs")
+            check(f"discard + render_resolved, call {rep}")
         rt.bindAccum(None, 0, 0)
         # main.cpp:135-151: three frames through the running-mean converter, against the oracle's PixelConversion
         k = int(rng.integers(1, 6))
