@@ -96,13 +96,15 @@ struct rt_ctx {
     bool lists_valid = false;
     ListKey lists_key{};
     uint32_t scene_version = 0;          // counts the builds of the device copy of the scene
-    // Whether the lists pay: the kernels that use them count their waves' steps and primary steps (two sums in device
-    // memory that only grow); a copy comes back to pinned host memory whenever a plan is renewed, and a view of
-    // which fewer than LISTS_MIN_SHARE of the steps were primary (long paths: an enclosed scene) goes on without lists.
-    unsigned long long* d_step_counts = nullptr;
-    unsigned long long* h_step_counts = nullptr;     // pinned: {steps, primary steps} as last copied
-    unsigned long long seen_steps = 0, seen_psteps = 0;
-    bool lists_useless = false;
+    // Whether the lists pay.  The second call in a row of a view that has lists runs the counting instance of the
+    // kernel (the one rt_render_stats uses: the same words, a tenth slower) and its counters come back to pinned host
+    // memory; a later call finds them there, and a view of which fewer than LISTS_MIN_SHARE of the waves' steps were
+    // primary steps (long paths: an enclosed scene) goes on without lists.  A camera that moves every frame is never
+    // measured and keeps its lists.
+    unsigned long long* h_stats_copy = nullptr;      // pinned, ST_COUNT words
+    hipEvent_t stats_copied = nullptr;               // recorded behind the copy
+    uint32_t view_streak = 0;                        // calls in a row that found the lists made
+    bool lists_measured = false, measure_pending = false, lists_useless = false;
 
     int compute_units = 0;
     uint32_t lds_limit = rtd::LDS_WORKGROUP_MAX_BYTES;   // what a workgroup can have of a CU's LDS on this device (hipDeviceProp_t::sharedMemPerBlock, at most 160 KiB)
@@ -604,8 +606,8 @@ void rt_destroy(rt_ctx* ctx)
     (void)hipFree(ctx->d_tile_cost);
     (void)hipFree(ctx->d_tile_order);
     (void)hipFree(ctx->d_tile_lists);
-    (void)hipFree(ctx->d_step_counts);
-    (void)hipHostFree(ctx->h_step_counts);
+    if (ctx->h_stats_copy) (void)hipHostFree(ctx->h_stats_copy);
+    if (ctx->stats_copied) (void)hipEventDestroy(ctx->stats_copied);
     (void)hipFree(ctx->d_stage);
     delete ctx;
 }
@@ -845,22 +847,19 @@ static int ensure_lists(rt_ctx* ctx, const rtd::TraceParams& P, const uint32_t**
         RT_HIP(ctx, hipMalloc(&ctx->d_tile_lists, sizeof(uint32_t) * rtd::TLIST_WORDS * (size_t)n_wt));
         ctx->lists_cap = n_wt;
     }
-    if (!ctx->d_step_counts) {
-        RT_HIP(ctx, hipMalloc(&ctx->d_step_counts, 2 * sizeof(unsigned long long)));
-        RT_HIP(ctx, hipMemsetAsync(ctx->d_step_counts, 0, 2 * sizeof(unsigned long long), ctx->stream));
-        RT_HIP(ctx, hipHostMalloc(&ctx->h_step_counts, 2 * sizeof(unsigned long long)));
-        ctx->h_step_counts[0] = ctx->h_step_counts[1] = 0;
-    }
-    // what the counts say that came back since the last look (they may be a call or two old: this only steers speed)
-    const unsigned long long steps = ctx->h_step_counts[0], psteps = ctx->h_step_counts[1];
-    if (steps > ctx->seen_steps && psteps >= ctx->seen_psteps) {
-        ctx->lists_useless = (double)(psteps - ctx->seen_psteps) < LISTS_MIN_SHARE * (double)(steps - ctx->seen_steps);
-        ctx->seen_steps = steps; ctx->seen_psteps = psteps;
+    // the counters of the measuring call, once they have come back (this only steers speed: any choice gives the same words)
+    if (ctx->measure_pending && hipEventQuery(ctx->stats_copied) == hipSuccess) {
+        const unsigned long long steps = ctx->h_stats_copy[rtd::ST_WAVE_ITERS], psteps = ctx->h_stats_copy[rtd::ST_PRIMARY_STEPS];
+        if (steps != 0) ctx->lists_useless = (double)psteps < LISTS_MIN_SHARE * (double)steps;
+        ctx->measure_pending = false;
     }
     if (!ctx->lists_valid || memcmp(&key, &ctx->lists_key, sizeof key) != 0) {
         RT_HIP(ctx, rtd::launch_tile_lists(ctx->stream, P, ctx->d_blob, ctx->d_tile_lists));
         ctx->lists_key = key; ctx->lists_valid = true;
-        ctx->lists_useless = false;                        // a new view: to be found out again
+        ctx->lists_useless = false; ctx->lists_measured = false; ctx->measure_pending = false;   // a new view: to be found out again
+        ctx->view_streak = 0;
+    } else {
+        ++ctx->view_streak;
     }
     if (!ctx->lists_useless) *out = ctx->d_tile_lists;
     return RT_OK;
@@ -971,15 +970,27 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         const uint32_t* lists = nullptr;
         rc = ensure_lists(ctx, P, &lists);
         if (rc) { if (d_timeline) (void)hipFree(d_timeline); return rc; }
-        P.step_counts = lists ? ctx->d_step_counts : nullptr;
+        // the view's second call in a row: count its steps (see rt_ctx::h_stats_copy)
+        const bool measure = lists != nullptr && !stats && !timeline_host && ctx->view_streak >= 1u && !ctx->lists_measured && spp >= ctx->lists_min_spp;
+        if (measure) {
+            if (!ctx->h_stats_copy) {
+                RT_HIP(ctx, hipHostMalloc(&ctx->h_stats_copy, sizeof(unsigned long long) * rtd::ST_COUNT));
+                RT_HIP(ctx, hipEventCreateWithFlags(&ctx->stats_copied, hipEventDisableTiming));
+            }
+            RT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * rtd::ST_COUNT, ctx->stream));
+        }
         const bool will_probe = !have_plan && !timeline_host && !ctx->env_no_probe && !ctx->env_no_tile_order && spp >= PROBE_MIN_SPP;
-        rc = trace_frame(ctx, P, accum_ptr(ctx), stats ? 1 : 0, replan ? ctx->d_tile_cost : nullptr, ctx->d_tile_order, have_plan,
+        rc = trace_frame(ctx, P, accum_ptr(ctx), (stats || measure) ? 1 : 0, replan ? ctx->d_tile_cost : nullptr, ctx->d_tile_order, have_plan,
                          !timeline_host && !ctx->env_no_probe && !ctx->env_no_tile_order, replan, &plan_units, d_timeline, lists);
         // resolved by the launch itself unless a probe's plan may have cut tiles (trace_frame then dropped the request)
         resolved_in_launch = P.resolve_out != nullptr && !(will_probe && slices_allowed(ctx, spp - (ctx->probe_spp ? ctx->probe_spp : PROBE_SPP)) > 1u);
         if (replan) { ctx->plan_view = view; ctx->plan_age = 0; } else ++ctx->plan_age;
-        if (replan && lists && rc == RT_OK)
-            (void)hipMemcpyAsync(ctx->h_step_counts, ctx->d_step_counts, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+        if (measure && rc == RT_OK) {
+            ctx->lists_measured = true;
+            if (hipMemcpyAsync(ctx->h_stats_copy, ctx->d_stats, sizeof(unsigned long long) * rtd::ST_COUNT, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                hipEventRecord(ctx->stats_copied, ctx->stream) == hipSuccess)
+                ctx->measure_pending = true;
+        }
         if (rc) { if (d_timeline) (void)hipFree(d_timeline); return rc; }
         hipError_t le = hipSuccess;
         if (d_timeline) {

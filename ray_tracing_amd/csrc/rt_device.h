@@ -52,13 +52,16 @@ namespace rtd {
 #ifndef RT_TREE_FAN
 #define RT_TREE_FAN 8
 #endif
+#ifndef RT_MAX_TREE_LEVELS
+#define RT_MAX_TREE_LEVELS 8
+#endif
 // The walk handles the four levels 0 .. 3 with its queues and stacks.  A mesh whose level 3 would have more than
 // TREE_TOP_MAX nodes (some 65 000 triangles and more) gets further levels on top, up to MAX_TREE_LEVELS in all, until the
 // top one is that short: the wave descends through those together, depth first, and enters the level-3 nodes that any
 // of its rays can touch (SceneLayout::tree_levels; 4 for every smaller mesh, whose upper levels may hold a single node).
 // (Measured with a sheet of 20 000 triangles, ten level-3 nodes: a fifth level costs 8 % — scanning ten nodes is
 // cheaper than the shared stack —; with 199 712 triangles, 98 level-3 nodes: two more levels save 11 %.)
-constexpr uint32_t TREE_LEAF = RT_TREE_LEAF, TREE_FAN = RT_TREE_FAN, TREE_LEVELS = 4, MAX_TREE_LEVELS = 8, TREE_TOP_MAX = 32;
+constexpr uint32_t TREE_LEAF = RT_TREE_LEAF, TREE_FAN = RT_TREE_FAN, TREE_LEVELS = 4, MAX_TREE_LEVELS = RT_MAX_TREE_LEVELS, TREE_TOP_MAX = 32;
 constexpr uint32_t SMALL_MESH_TRIS = 800u;
 constexpr uint32_t TREE_LEAF_SMALL = TREE_LEAF >= 2u ? TREE_LEAF / 2u : TREE_LEAF;
 static_assert((TREE_LEAF & (TREE_LEAF - 1u)) == 0u, "a leaf holds a power of two of triangles (lanes of a pass find theirs by shift and mask)");
@@ -101,9 +104,6 @@ struct TraceParams {
     // writes its pixel's mean as resolve_kernel would.  resolve_out = nullptr: no resolve.
     uint32_t resolve_samples, resolve_gamma, resolve_flip;
     float*   resolve_out;
-    // Instances with primary steps add their waves' steps and primary steps here (two 64-bit sums that only grow):
-    // the host reads them now and then and stops handing out lists to a view whose steps are hardly ever primary.
-    unsigned long long* step_counts;
     SceneLayout scene;
 };
 
@@ -120,7 +120,10 @@ enum { ST_SAMPLES = 0, ST_SEGMENTS, ST_DIFFUSE, ST_SPECULAR, ST_TERMINAL, ST_TRI
 //   word 2..5: spheres, bit s of the 128 = sphere s in upload order among the spheres
 //   word 6..: the leaves
 // A scene with more spheres or boxes than the masks hold has no lists.
-constexpr uint32_t TLIST_WORDS = 32u, TLIST_SPH_WORDS = 4u, TLIST_LEAF0 = 2u + TLIST_SPH_WORDS, TLIST_MAX_LEAVES = TLIST_WORDS - TLIST_LEAF0,
+#ifndef RT_TLIST_SPH_WORDS
+#define RT_TLIST_SPH_WORDS 4
+#endif
+constexpr uint32_t TLIST_WORDS = 32u, TLIST_SPH_WORDS = RT_TLIST_SPH_WORDS, TLIST_LEAF0 = 2u + TLIST_SPH_WORDS, TLIST_MAX_LEAVES = TLIST_WORDS - TLIST_LEAF0,
                    TLIST_NONE = 0xffffffffu, TLIST_MAX_SPHERES = 32u * TLIST_SPH_WORDS, TLIST_MAX_BOXES = 32u;
 // A wave takes a primary step — only its lanes that are about to trace a camera ray take part, and they test the
 // tile's candidates instead of walking the scene — when all its live lanes are such, or at least this many.

@@ -648,6 +648,11 @@ void trace_kernel(const TraceParams P,
     constexpr bool PSTEP = (GEO & 32) != 0;
     // A mesh (in global memory) whose tree has levels above the walk's four: an instance of its own as well (GEO bit 6).
     constexpr bool DEEP_TREE = (GEO & 64) != 0;
+    // The candidate spheres of a tile are bits of up to four words.  The sphere-only instances are built twice: for
+    // scenes of up to 32 spheres (one word, kept in a register: the loop every small scene runs, and the headline's) and
+    // for larger ones (GEO bit 7); their loop is short enough for the difference to show (3 % on the four-sphere scene).
+    constexpr bool MANY_SPH = (GEO & 128) != 0 || (GEO & 3) != 0;
+    static_assert((GEO & 128) == 0 || (PSTEP && (GEO & 3) == 0), "more than 32 candidate spheres: a sphere-only instance with primary steps");
     static_assert(!DEEP_TREE || ((GEO & 3) == 2 && (GEO & 8) == 0), "upper tree levels: a mesh in global memory, counter hash");
     static_assert(!PSTEP || (!RNG_GLSL && (GEO & 16) == 0), "primary steps: counter hash, recipe arithmetic");
     extern __shared__ float4 lds[];
@@ -832,17 +837,17 @@ void trace_kernel(const TraceParams P,
     // alone (the others wait one step): they test the tile's candidates directly, no bounds, no queues.  The
     // candidates include every primitive whose test could accept such a ray, the closest hit is the same minimum
     // of (distance, index): the same words.  A step with fewer camera rays is an ordinary iteration for everyone.
-    uint32_t pl_box = 0u, pl_n = TLIST_NONE;
+    uint32_t pl_box = 0u, pl_n = TLIST_NONE, pl_sph0 = 0u;            // (the first 32 spheres' bits are kept at hand: most scenes have no more)
     const uint32_t* pl_sph = nullptr;                                 // TLIST_SPH_WORDS words
     const uint32_t* pl_leaves = nullptr;
     if (PSTEP && tile_lists) {
         const uint32_t wt = __builtin_amdgcn_readfirstlane((tile_y * 2u + (sub >> 1)) * (2u * P.tiles_x) + tile_x * 2u + (sub & 1u));
         const uint32_t* const rec_ = tile_lists + (size_t)wt * TLIST_WORDS;
         pl_n = rec_[0]; pl_box = rec_[1]; pl_sph = rec_ + 2; pl_leaves = rec_ + TLIST_LEAF0;
+        pl_sph0 = rec_[2];
     }
     const uint32_t pl_sph_words = (L.n_sph + 31u) >> 5;               // mask words in use
     const bool have_list = PSTEP && pl_n != TLIST_NONE;
-    uint32_t my_steps = 0u;                                           // of this lane's time in the loop: steps | primary steps << 16 (a wave's steps stay far below 65 536; beyond, the counts are off, which only blurs a heuristic)
 #if RT_PHASE_CLOCKS
     uint32_t phase_clk[4] = { 0u, 0u, 0u, 0u }, phase_t = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
@@ -854,7 +859,6 @@ void trace_kernel(const TraceParams P,
             const uint32_t n_all = (uint32_t)__popcll(__ballot(1)), n_first = (uint32_t)__popcll(__ballot(bounce == 0u));
             pstep = n_first == n_all || n_first >= PSTEP_MIN;
         }
-        if (PSTEP) my_steps += pstep ? 0x10001u : 1u;
         if (!pstep || bounce == 0u) {
         if (STATS && pstep && lane_is_first()) ++n_psteps;
         // ---- closest hit: Scene::hit (scene.h:232-255) /
@@ -900,11 +904,19 @@ void trace_kernel(const TraceParams P,
         }
         if (PSTEP && pstep) {
             // the tile's candidate spheres, in upload order (a later one replaces the best only by a strictly smaller key)
-            for (uint32_t w = 0; w < pl_sph_words; ++w) {
-                for (uint32_t m = pl_sph[w]; m != 0u; m &= m - 1u) {
-                    const uint32_t i = 32u * w + (uint32_t)__builtin_ctz(m);
+            if (!MANY_SPH) {
+                for (uint32_t m = pl_sph0; m != 0u; m &= m - 1u) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(m);
                     test_sphere<SEM>(sph[i], reinterpret_cast<const uint32_t*>(sid)[i], o, d, best);
                     if (STATS) ++n_sph_test;
+                }
+            } else {
+                for (uint32_t w = 0; w < pl_sph_words; ++w) {
+                    for (uint32_t m = w == 0u ? pl_sph0 : pl_sph[w]; m != 0u; m &= m - 1u) {
+                        const uint32_t i = 32u * w + (uint32_t)__builtin_ctz(m);
+                        test_sphere<SEM>(sph[i], reinterpret_cast<const uint32_t*>(sid)[i], o, d, best);
+                        if (STATS) ++n_sph_test;
+                    }
                 }
             }
         }
@@ -1464,16 +1476,6 @@ void trace_kernel(const TraceParams P,
             }
         }
     }
-    if (PSTEP && !TRACE && P.step_counts != nullptr) {
-        // the wave's counts are those of its longest-lived lane
-        uint32_t st_ = my_steps;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const uint32_t os = (uint32_t)__shfl_down(st_, off, 64);
-            st_ = (os & 0xffffu) > (st_ & 0xffffu) ? os : st_;
-        }
-        if (lane == 0u && st_ != 0u) { atomicAdd(&P.step_counts[0], (unsigned long long)(st_ & 0xffffu)); atomicAdd(&P.step_counts[1], (unsigned long long)(st_ >> 16)); }
-    }
     // What this tile cost, for the next frame's launch order: the longest of its four waves' loops.
     if (!TRACE && tile_cost && lane == 0u)
         atomicMax(&tile_cost[tile], (COST_CLOCK ? (uint32_t)((__builtin_amdgcn_s_memtime() - c_start) >> 8) + 1u : iterations) * n_slices);
@@ -1688,8 +1690,8 @@ void tile_lists_kernel(const TraceParams P, const float4* __restrict__ blob, uin
         }
         return in;
     };
-    uint32_t sph_mask[TLIST_SPH_WORDS] = { 0u, 0u, 0u, 0u }, box_mask = 0u;
-    static_assert(TLIST_SPH_WORDS == 4u, "initialiser above");
+    uint32_t sph_mask[TLIST_SPH_WORDS], box_mask = 0u;
+    for (uint32_t w = 0; w < TLIST_SPH_WORDS; ++w) sph_mask[w] = 0u;
     for (uint32_t i = 0; i < L.n_sph; ++i) {
         const float4 sp = blob[L.sph_off + i];
         const double c[3] = { sp.x, sp.y, sp.z }, R = sqrt((double)sp.w);
@@ -1860,7 +1862,7 @@ hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams
                     (P.rng_mode ? 8 : 0) | ((P.flags & RT_FLAG_LITERAL_GEOMETRY) != 0u ? 16 : 0) |
                     ((RT_PSTEP != 0 && tile_lists != nullptr && P.rng_mode == 0 && (P.flags & RT_FLAG_LITERAL_GEOMETRY) == 0u && mode != 2) ? 32 : 0);
     if ((geo & 32) == 0) tile_lists = nullptr;
-    const int deep = (tri_mode == 2 && P.scene.tree_levels > TREE_LEVELS) ? 64 : 0;          // (never with the shader's own stream: rt_api.cpp keeps such a tree at four levels)
+    const int deep = ((tri_mode == 2 && P.scene.tree_levels > TREE_LEVELS) ? 64 : 0) | (((geo & 32) != 0 && tri_mode == 0 && P.scene.n_sph > 32u) ? 128 : 0);          // (never with the shader's own stream: rt_api.cpp keeps such a tree at four levels)
 #define RT_CASE(S, G, M) if (sem == S && (geo | deep) == G && mode == M) return launch_one<S, G, M>(grid, lds_bytes, stream, P, b, accum, st, th, tm, tile_order, tile_cost, tile_lists)
 #define RT_CASES(S, G) RT_CASE(S, G, 0); RT_CASE(S, G, 1); RT_CASE(S, G, 2)
 #define RT_GEOS(S) RT_CASES(S, 0); RT_CASES(S, 1); RT_CASES(S, 2); RT_CASES(S, 4); RT_CASES(S, 5); RT_CASES(S, 6); \
@@ -1872,6 +1874,7 @@ hipError_t launch_trace(int sem, int mode, hipStream_t stream, const TraceParams
     RT_PCASES(1, 32); RT_PCASES(1, 33); RT_PCASES(1, 34); RT_PCASES(1, 36); RT_PCASES(1, 37); RT_PCASES(1, 38);
     RT_CASES(0, 66); RT_CASES(0, 70); RT_PCASES(0, 98); RT_PCASES(0, 102);                 // ... and a tree of more than four levels
     RT_CASES(1, 66); RT_CASES(1, 70); RT_PCASES(1, 98); RT_PCASES(1, 102);
+    RT_PCASES(0, 160); RT_PCASES(0, 164); RT_PCASES(1, 160); RT_PCASES(1, 164);          // ... and sphere-only scenes of more than 32 spheres
 #undef RT_PCASES
 #undef RT_GEOS
 #undef RT_CASES
