@@ -171,6 +171,8 @@ typedef struct rt_stats {
     uint64_t box_bound_tests_done; /* slab tests of those bounds it executed to do so */
     uint64_t sphere_tests_done;    /* ray-sphere tests this library executed (camera rays test only the spheres their tile can see) */
     uint64_t primary_steps;        /* of wave_iterations: steps that traced camera rays only, from their tile's candidate list */
+    uint64_t tree_entries;         /* times a wave entered a top node of the mesh's tree (some lane's ray touched its bound) */
+    uint64_t tree_entering_lanes;  /* ... and the lanes whose rays did: tree_entering_lanes / tree_entries lanes share a walk */
 } rt_stats;
 
 typedef struct rt_ctx rt_ctx;

@@ -43,7 +43,7 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "segments", "diffuse", "specular", "terminal",
                                           "shape_tests", "sphere_tests", "box_tests", "triangle_tests",
                                           "triangle_tests_done", "bound_tests_done", "wave_iterations", "work_units",
-                                          "box_tests_done", "box_bound_tests_done", "sphere_tests_done", "primary_steps")]
+                                          "box_tests_done", "box_bound_tests_done", "sphere_tests_done", "primary_steps", "tree_entries", "tree_entering_lanes")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -1031,6 +1031,8 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         stats->box_bound_tests_done = h[rtd::ST_BOX_BOUNDS];
         stats->sphere_tests_done = h[rtd::ST_SPHERE_TESTS];
         stats->primary_steps = h[rtd::ST_PRIMARY_STEPS];
+        stats->tree_entries = h[rtd::ST_TREE_ENTRIES];
+        stats->tree_entering_lanes = h[rtd::ST_TREE_ENTERING_LANES];
     }
     return RT_OK;
 }

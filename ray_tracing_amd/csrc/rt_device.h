@@ -109,7 +109,7 @@ struct TraceParams {
 
 // Slots of the statistics block (uint64 each).
 enum { ST_SAMPLES = 0, ST_SEGMENTS, ST_DIFFUSE, ST_SPECULAR, ST_TERMINAL, ST_TRI_TESTS, ST_NODE_TESTS, ST_WAVE_ITERS, ST_UNITS, ST_BOX_TESTS, ST_BOX_BOUNDS,
-       ST_SPHERE_TESTS, ST_PRIMARY_STEPS, ST_COUNT };
+       ST_SPHERE_TESTS, ST_PRIMARY_STEPS, ST_TREE_ENTRIES, ST_TREE_ENTERING_LANES, ST_COUNT };
 
 // Candidate lists of the camera rays, one record per 8x8-pixel wave tile (tile_lists_kernel makes them once per scene,
 // camera and frame size; trace_kernel's "primary steps" read them): every primitive that a camera ray through the
@@ -162,13 +162,20 @@ constexpr uint32_t QUEUE_ENTRIES = 128u, SPREAD_BELOW = RT_SPREAD_BELOW;
 #ifndef RT_NODE_STACK_STAGED
 #define RT_NODE_STACK_STAGED 32u
 #endif
-constexpr uint32_t NODE_STACK_STAGED = RT_NODE_STACK_STAGED, NODE_STACK_GLOBAL = 256u;
+// A pass over queued nodes gives TREE_FAN / NODE_CPL lanes to each triple, every lane testing NODE_CPL children: fewer,
+// fuller passes (a pass costs some 60 instructions around its tests).
+#ifndef RT_NODE_CPL
+#define RT_NODE_CPL 1
+#endif
+constexpr uint32_t NODE_CPL = RT_NODE_CPL, NODE_LPT = TREE_FAN / NODE_CPL;
+static_assert(NODE_CPL >= 1u && NODE_LPT * NODE_CPL == TREE_FAN, "children per lane must divide the fan-out");
+constexpr uint32_t NODE_STACK_STAGED = RT_NODE_STACK_STAGED, NODE_STACK_GLOBAL = 256u * NODE_CPL;
 // What is left below a full pass, plus what one step can add, must fit (64 lanes; a pass takes 64 / TREE_LEAF pairs
 // or 64 / TREE_FAN triples and can put 64 new ones there; three levels above the leaves).
 static_assert(TREE_LEAF >= 1u && TREE_LEAF <= 64u && TREE_FAN >= 2u && TREE_FAN <= 64u && SPREAD_BELOW <= 64u, "tree shape");
 static_assert((64u / TREE_LEAF_SMALL - 1u) + 64u <= QUEUE_ENTRIES, "the leaf queue overflows");
-static_assert((64u / TREE_FAN - 1u) + (SPREAD_BELOW - 1u) <= NODE_STACK_STAGED, "the node stack of a staged mesh overflows");
-static_assert((64u / TREE_FAN - 1u) + (SPREAD_BELOW - 1u) + (TREE_LEVELS - 2u) * (64u - 64u / TREE_FAN) + 64u <= NODE_STACK_GLOBAL,
+static_assert((64u / NODE_LPT - 1u) + (SPREAD_BELOW - 1u) <= NODE_STACK_STAGED, "the node stack of a staged mesh overflows");
+static_assert((64u / NODE_LPT - 1u) + (SPREAD_BELOW - 1u) + (TREE_LEVELS - 2u) * (64u * NODE_CPL - 64u / NODE_LPT) + 64u * NODE_CPL <= NODE_STACK_GLOBAL,
               "the node stack of a mesh in global memory overflows");
 static_assert(TREE_LEVELS == 4u, "stack entries carry two bits of level, the walk has four nested loops");
 // Behind them, while the wave's lanes share its paths: the sums of the wave's 64 pixels, three 32-bit words each,

@@ -90,6 +90,7 @@ namespace rtd {
 #ifndef RT_PSTEP
 #define RT_PSTEP 1
 #endif
+
 struct V3 { float x, y, z; };
 constexpr uint32_t WORK_NONE = 0xffffffffu;      // a plan entry without work
 
@@ -659,7 +660,7 @@ void trace_kernel(const TraceParams P,
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     uint32_t n_samples = 0, n_segments = 0, n_diffuse = 0, n_specular = 0, n_terminal = 0, n_tri = 0, n_node = 0, n_iterations = 0, n_box_test = 0, n_box_bound = 0,
-             n_sph_test = 0, n_psteps = 0;
+             n_sph_test = 0, n_psteps = 0, n_tree_entries = 0, n_tree_lanes = 0;
 
     // One 8x8-pixel tile per wave, four waves (a 16x16 tile) per workgroup; workgroups start in
     // blockIdx order.  `work` is the plan made from the previous frame of this view (tile_plan_kernel):
@@ -1091,7 +1092,7 @@ void trace_kernel(const TraceParams P,
             // stack, where the next pass finds it first — depth first, which bounds the stack (see rt_device.h).
             // A staged mesh is small: only its level-1 nodes are worth queueing.
             constexpr bool DEEP = TRI_GLOBAL;
-            const uint32_t node_pass = n_live / TREE_FAN;         // triples one pass takes: TREE_FAN lanes each
+            const uint32_t node_pass = n_live / NODE_LPT;         // triples one pass takes: NODE_LPT lanes each
             uint32_t ns_len = 0u;                                  // wave-uniform
             auto push_nodes = [&](bool touch, uint32_t src, uint32_t level, uint32_t node) {
                 const unsigned long long touching = __ballot(touch);
@@ -1103,12 +1104,12 @@ void trace_kernel(const TraceParams P,
             };
             auto bound_pass = [&](uint32_t count) {
                 RT_PHASE_MARK3(1)
-                const uint32_t e = lane_rank / TREE_FAN, c = lane_rank % TREE_FAN;
+                const uint32_t e = lane_rank / NODE_LPT, c = (lane_rank % NODE_LPT) * NODE_CPL;
                 const bool work = e < count;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const uint32_t ent = work ? node_stack[ns_len - count + e] : ((lane << 26) | (1u << 24));
                 ns_len -= count;                                   // popped: what the pass pushes may take their place
-                const uint32_t src = ent >> 26, level = DEEP ? (ent >> 24) & 3u : 1u, child = TREE_FAN * (ent & 0xffffffu) + c;
+                const uint32_t src = ent >> 26, level = DEEP ? (ent >> 24) & 3u : 1u, child0 = TREE_FAN * (ent & 0xffffffu) + c;
                 const int from = (int)(src << 2);
                 const V3 ro = v3(__uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(o.x))),
                                  __uint_as_float(__builtin_amdgcn_ds_bpermute(from, __float_as_uint(o.y))),
@@ -1120,12 +1121,16 @@ void trace_kernel(const TraceParams P,
                 // the children live one level down
                 const uint32_t n_children = level == 1u ? L.node_n[0] : (level == 2u ? L.node_n[1] : L.node_n[2]);
                 const uint32_t children_at = level == 1u ? L.node_off[0] : (level == 2u ? L.node_off[1] : L.node_off[2]);
-                const bool valid = work && child < n_children;
-                const bool touch = valid && (!cull || bound_hit<SEM>(nodes[children_at + (valid ? child : 0u)], ro, rd, rkey));
-                if (STATS && valid) ++n_node;
-                if (DEEP) push_nodes(touch && level != 1u, src, level - 1u, child);
-                RT_PHASE_MARK3(2)
-                push_leaves(touch && level == 1u, src, child);
+#pragma unroll
+                for (uint32_t cc = 0; cc < NODE_CPL; ++cc) {
+                    const uint32_t child = child0 + cc;
+                    const bool valid = work && child < n_children;
+                    const bool touch = valid && (!cull || bound_hit<SEM>(nodes[children_at + (valid ? child : 0u)], ro, rd, rkey));
+                    if (STATS && valid) ++n_node;
+                    if (DEEP) push_nodes(touch && level != 1u, src, level - 1u, child);
+                    RT_PHASE_MARK3(2)
+                    push_leaves(touch && level == 1u, src, child);
+                }
             };
             // -> the node was put on the stack (few lanes touch it) and full passes were run
             auto queue_node = [&](bool touch, uint32_t n_touching, uint32_t level, uint32_t node) -> bool {
@@ -1175,6 +1180,7 @@ void trace_kernel(const TraceParams P,
                 const bool touch3 = !cull || bound_hit<SEM>(node3[i3], o, d, best.key);
                 const unsigned long long touching3 = __ballot(touch3);
                 if (touching3 == 0ull) continue;
+                if (STATS) { if (lane_is_first()) ++n_tree_entries; n_tree_lanes += touch3 ? 1u : 0u; }
                 if (DEEP && queue_node(touch3, (uint32_t)__popcll(touching3), 3u, i3)) continue;
                 const uint32_t e2 = min(TREE_FAN * i3 + TREE_FAN, L.node_n[2]);
                 for (uint32_t i2 = TREE_FAN * i3; i2 < e2; ++i2) {
@@ -1504,7 +1510,7 @@ void trace_kernel(const TraceParams P,
     if (STATS) {
         // Sum over the wave with cross-lane shuffles, one atomic per wave and counter.
         uint32_t c[ST_COUNT] = { n_samples, n_segments, n_diffuse, n_specular, n_terminal, n_tri, n_node, (lane == 0u) ? n_iterations : 0u,
-                                 (lane == 0u && (q & 3u) == 0u) ? 1u : 0u, n_box_test, n_box_bound, n_sph_test, n_psteps };
+                                 (lane == 0u && (q & 3u) == 0u) ? 1u : 0u, n_box_test, n_box_bound, n_sph_test, n_psteps, n_tree_entries, n_tree_lanes };
 #pragma unroll
         for (int k = 0; k < ST_COUNT; ++k) {
             unsigned long long v = c[k];

@@ -14,4 +14,5 @@ wi, ps = st["wave_iterations"], st["primary_steps"]
 print(name, kw, {k: v for k, v in st.items()})
 print(f"  steps {wi}, primary {ps} ({ps / wi:.3f}); per other step: bound tests {st['bound_tests_done'] / max(1, wi - ps):.1f}, "
       f"triangle tests {st['triangle_tests_done'] / max(1, wi - ps):.1f}, box bounds {st['box_bound_tests_done'] / max(1, wi - ps):.1f}, "
-      f"box tests {st['box_tests_done'] / max(1, wi - ps):.1f}, sphere tests {st['sphere_tests_done'] / max(1, wi):.1f} per step")
+      f"box tests {st['box_tests_done'] / max(1, wi - ps):.1f}, sphere tests {st['sphere_tests_done'] / max(1, wi):.1f} per step; "
+      f"the tree was entered in {st['tree_entries'] / max(1, wi - ps):.3f} of the other steps, by {st['tree_entering_lanes'] / max(1, st['tree_entries']):.1f} lanes on average")
