@@ -791,7 +791,7 @@ void trace_kernel(const TraceParams P,
     const float4* const tri = TRI_GLOBAL ? blob + L.tri_off : lds + L.tri_off;
     const uint32_t* const slot_of = reinterpret_cast<const uint32_t*>(blob + L.inv_off);        // read once per triangle hit: global memory
     // The tree over a staged mesh is staged with it; that of a mesh in global memory is read from there too
-    // (measured on the 4 968-triangle mesh: where its tree lives makes no difference, 120-123 ms either way).
+    // (measured on the 4 968-triangle mesh: where its tree lives makes no difference to the frame time).
     const float4* const nodes = TRI_GLOBAL ? blob : lds;
     const float4* const node0 = nodes + L.node_off[0];
     const float4* const node1 = nodes + L.node_off[1];
@@ -1087,8 +1087,8 @@ void trace_kernel(const TraceParams P,
                 while (q_len >= per_pass) { pass(per_pass); q_head += per_pass; q_len -= per_pass; }
             };
             // The same further up: a node that few lanes touch is put on the wave's stack as (lane, level, node), and a
-            // pass gives eight lanes to each pair on top of the stack, one per child: they test the child's bound
-            // against the pair's ray.  A touched leaf goes to the triangle queue, a touched inner node back onto the
+            // pass gives NODE_LPT lanes to each triple on top of the stack, NODE_CPL children each: they test the
+            // child's bound against the triple's ray.  A touched leaf goes to the triangle queue, a touched inner node back onto the
             // stack, where the next pass finds it first — depth first, which bounds the stack (see rt_device.h).
             // A staged mesh is small: only its level-1 nodes are worth queueing.
             constexpr bool DEEP = TRI_GLOBAL;
