@@ -534,7 +534,10 @@ def main():
                          "exhaustive_scan_flops_per_launch": algorithmic_flops(stats, executed=False),
                          "algorithmic_hbm_bytes_per_launch": cfg.width * cfg.height * 32,
                          "valu_issue": issue,
-                         "note": "fp32 vector (VALU) bound: no dense contraction, no MFMA; HBM traffic is the framebuffer only"},
+                         "note": "fp32 vector (VALU) bound: no dense contraction, no MFMA; HBM traffic is the framebuffer only. "
+                                 "achieved prices the tests the kernel executed (camera rays test their tile's candidates only, "
+                                 "triangles and boxes are culled by their bounds); exhaustive_scan_flops_per_launch prices the "
+                                 "reference's scan of every primitive for every segment of the same paths"},
         }
         if other is not None:
             result["other_split"] = other

@@ -1063,7 +1063,7 @@ int rt_render_noalloc(rt_ctx* ctx, void* accum_device, uint32_t width, uint32_t 
     // The candidate lists of the camera rays live in memory rt_render allocates: this call takes those an earlier
     // rt_render of the same view left, or traces without them (the same words, more slowly on scenes with boxes or a mesh).
     const uint32_t* lists = nullptr;
-    if (ctx->lists_valid && !ctx->env_no_tile_lists && P.rng_mode == 0) {
+    if (ctx->lists_valid && !ctx->lists_useless && !ctx->env_no_tile_lists && P.rng_mode == 0) {
         rt_ctx::ListKey key{};
         memcpy(key.cam, P.cam, sizeof key.cam);
         key.width = P.width; key.height = P.height; key.sample_mode = P.sample_mode; key.grid_n = P.grid_n;

@@ -945,7 +945,7 @@ void trace_kernel(const TraceParams P,
         const bool spread = HAS_QUEUES && n_live >= 16u;             // fewer live lanes: every test as a wave
         // Boxes.  The full test is long (three reciprocals, three candidate points); a lane needs it only for a box
         // whose bounds its ray touches (a slab test).  Those (lane, box) pairs are queued and tested one lane per pair.
-        if (PSTEP && pstep) {
+        if (HAS_QUEUES && PSTEP && pstep) {
             // the tile's candidate boxes: the exact test by every lane of the step, no bounds first
             for (uint32_t m = pl_box; m != 0u; m &= m - 1u) {
                 const uint32_t i = (uint32_t)__builtin_ctz(m);
@@ -1032,7 +1032,7 @@ void trace_kernel(const TraceParams P,
         // triangle, each fetching the ray of the pair's lane across the wave.  A crossing goes to the slot of the
         // ray's lane by an atomic minimum on (key, id) — the same order-independent minimum as everywhere else —
         // and every lane folds its slot into its closest hit when the walk is over.
-        if (PSTEP && pstep) {
+        if (HAS_QUEUES && PSTEP && pstep) {
             // the tile's candidate leaves: their triangles by every lane of the step
             const uint32_t leaf_shift = L.leaf_shift, leaf_size = 1u << leaf_shift;
             for (uint32_t k = 0; k < pl_n; ++k) {
