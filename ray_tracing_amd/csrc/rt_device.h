@@ -52,6 +52,9 @@ namespace rtd {
 #ifndef RT_TREE_FAN
 #define RT_TREE_FAN 8
 #endif
+#ifndef RT_TREE_TOP_MAX
+#define RT_TREE_TOP_MAX 32         // a tree gets levels until its top one has at most this many nodes (1: test builds, deep trees over small meshes)
+#endif
 #ifndef RT_MAX_TREE_LEVELS
 #define RT_MAX_TREE_LEVELS 8
 #endif
@@ -60,8 +63,9 @@ namespace rtd {
 // top one is that short: the wave descends through those together, depth first, and enters the level-3 nodes that any
 // of its rays can touch (SceneLayout::tree_levels; 4 for every smaller mesh, whose upper levels may hold a single node).
 // (Measured with a sheet of 20 000 triangles, ten level-3 nodes: a fifth level costs 8 % — scanning ten nodes is
-// cheaper than the shared stack —; with 199 712 triangles, 98 level-3 nodes: two more levels save 11 %.)
-constexpr uint32_t TREE_LEAF = RT_TREE_LEAF, TREE_FAN = RT_TREE_FAN, TREE_LEVELS = 4, MAX_TREE_LEVELS = RT_MAX_TREE_LEVELS, TREE_TOP_MAX = 32;
+// cheaper than the shared stack —; with 199 712 triangles, 98 level-3 nodes, a fifth level makes no difference; with a
+// million triangles, 489 level-3 nodes, two more levels save a third of the frame.)
+constexpr uint32_t TREE_LEAF = RT_TREE_LEAF, TREE_FAN = RT_TREE_FAN, TREE_LEVELS = 4, MAX_TREE_LEVELS = RT_MAX_TREE_LEVELS, TREE_TOP_MAX = RT_TREE_TOP_MAX;
 constexpr uint32_t SMALL_MESH_TRIS = 800u;
 constexpr uint32_t TREE_LEAF_SMALL = TREE_LEAF >= 2u ? TREE_LEAF / 2u : TREE_LEAF;
 static_assert((TREE_LEAF & (TREE_LEAF - 1u)) == 0u, "a leaf holds a power of two of triangles (lanes of a pass find theirs by shift and mask)");
