@@ -38,12 +38,15 @@ PEAK_HBM_GBS = 8000.0
 PEAK_CLOCK_HZ, N_SIMD = 2.4e9, 1024
 
 
-def algorithmic_flops(st, executed=True):
-    """Flops of one launch.  executed=True prices the tests the kernel really ran (it culls triangles and boxes by
-    their bounds); executed=False prices the reference's exhaustive scan of every triangle and box."""
+def algorithmic_flops(st, executed=True, spheres_executed=False):
+    """Flops of one launch.  executed=True prices the triangle and box tests the kernel really ran (it culls them by
+    their bounds, and pays for the bound tests); executed=False prices the reference's exhaustive scan of every
+    triangle and box.  Spheres are priced as the reference's algorithm tests them — every sphere for every segment
+    (Scene::hit, scene.h:232-255; getClosestShapeIndex, RayTracing.glsl:206-231) — unless spheres_executed, which counts
+    the tests run: camera rays test only the spheres their tile can see."""
     tri = st["triangle_tests_done"] * F_TRI + st["bound_tests_done"] * F_BOUND if executed else st["triangle_tests"] * F_TRI
     box = st["box_tests_done"] * F_BOX + st["box_bound_tests_done"] * F_BOX_BOUND if executed else st["box_tests"] * F_BOX
-    sph = st["sphere_tests_done"] if executed else st["sphere_tests"]      # camera rays test only the spheres their tile can see
+    sph = st["sphere_tests_done"] if spheres_executed else st["sphere_tests"]
     return (st["samples"] * F_CAMERA + sph * F_SPHERE + box + tri +
             st["diffuse"] * F_DIFFUSE + st["specular"] * F_SPECULAR + st["terminal"] * F_TERMINAL)
 
@@ -449,6 +452,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = samples_per_step / (elapsed / args.steps) / 1e6
         flops = algorithmic_flops(stats)
+        executed_flops = algorithmic_flops(stats, spheres_executed=True)
         achieved = flops / (kernel_ms * 1e-3) / 1e12
         # Counters of the same launch from the committed rocprofv3 passes (profiles/traffic.json): HBM bytes, and
         # the vector instructions issued, which price the launch in issue slots of the vector pipe.
@@ -531,13 +535,18 @@ def main():
                          "frac": round(achieved / PEAK_FP32_VECTOR_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "trace_kernel", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_flops_per_launch": flops,
+                         "executed_flops_per_launch": executed_flops,
+                         "achieved_executed": round(executed_flops / (kernel_ms * 1e-3) / 1e12, 3),
+                         "frac_executed": round(executed_flops / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_VECTOR_TFLOPS, 4),
                          "exhaustive_scan_flops_per_launch": algorithmic_flops(stats, executed=False),
                          "algorithmic_hbm_bytes_per_launch": cfg.width * cfg.height * 32,
                          "valu_issue": issue,
                          "note": "fp32 vector (VALU) bound: no dense contraction, no MFMA; HBM traffic is the framebuffer only. "
-                                 "achieved prices the tests the kernel executed (camera rays test their tile's candidates only, "
-                                 "triangles and boxes are culled by their bounds); exhaustive_scan_flops_per_launch prices the "
-                                 "reference's scan of every primitive for every segment of the same paths"},
+                                 "achieved is the algorithmic work of the launch (measured segments and events; every sphere for every "
+                                 "segment, as the reference's closest-hit loop scans them; triangle, box and bound tests as executed: "
+                                 "those are culled by a tree the reference does not have) over the kernel's time. achieved_executed / "
+                                 "frac_executed count the sphere tests actually run (camera rays test only the spheres their tile can "
+                                 "see), exhaustive_scan_flops_per_launch the reference's scan of every primitive"},
         }
         if other is not None:
             result["other_split"] = other
