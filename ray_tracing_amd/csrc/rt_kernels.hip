@@ -1745,6 +1745,27 @@ void tile_lists_kernel(const TraceParams P, const float4* __restrict__ blob, uin
     rec[0] = overflow ? TLIST_NONE : n_leaf;
 }
 
+// What a 16x16 tile is likely to cost before anything has been traced, from the candidate lists of its four wave tiles:
+// 1 + leaf_weight x the largest number of candidate leaves among them (a list that overflowed counts as a full one).
+// A probe launch is planned from it (rt_api.cpp, trace_frame): without any plan the probe of a scene with a large mesh
+// lasts as long as the lone waves on the mesh's tiles at its end, whose passes each wait for memory with nothing to
+// hide it behind.  (Spreading the assumed cost to the tiles around, halved per tile of distance up to three — the floor
+// beside a mesh is expensive too, its rays bounce into it — was measured and made the cold frames slower.)
+__global__ void tile_prior_kernel(const TraceParams P, const uint32_t* __restrict__ lists, uint32_t* __restrict__ cost, uint32_t leaf_weight)
+{
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= P.tiles_x * P.tiles_y) return;
+    const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    uint32_t most = 0u;
+    for (uint32_t sub = 0; sub < 4u; ++sub) {
+        const uint32_t wtx = 2u * tx + (sub & 1u), wty = 2u * ty + (sub >> 1);
+        if (wtx * 8u >= P.width || wty * 8u >= P.owned_rows) continue;       // no pixel there
+        const uint32_t n = lists[(size_t)(wty * 2u * P.tiles_x + wtx) * TLIST_WORDS];
+        most = max(most, n == TLIST_NONE ? TLIST_MAX_LEAVES + 6u : n);
+    }
+    cost[tile] = 1u + leaf_weight * most;
+}
+
 // TRACE launches first mark every entry "path already over".
 __global__ void trace_fill_kernel(int32_t* hit, uint32_t* mat, size_t n)
 {
@@ -1847,6 +1868,13 @@ hipError_t launch_tile_lists(hipStream_t stream, const TraceParams& P, const voi
     return hipGetLastError();
 }
 
+hipError_t launch_tile_prior(hipStream_t stream, const TraceParams& P, const uint32_t* lists, uint32_t* cost, uint32_t leaf_weight)
+{
+    const uint32_t n = P.tiles_x * P.tiles_y;
+    if (n == 0u) return hipSuccess;
+    hipLaunchKernelGGL(tile_prior_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, P, lists, cost, leaf_weight);
+    return hipGetLastError();
+}
 hipError_t launch_tile_plan(hipStream_t stream, uint32_t* cost, uint32_t* work, uint32_t n, uint32_t extra, uint32_t max_slices, float share, float early_share)
 {
     hipLaunchKernelGGL(tile_plan_kernel, dim3(1), dim3(1024), 0, stream, cost, work, n, extra, max_slices, share, early_share);

@@ -405,6 +405,42 @@ def test_first_frame_of_a_fresh_context_equals_the_oracle(rta, orc):
         rt.close()
 
 
+def test_planned_probe_of_a_large_mesh(rta, orc, monkeypatch):
+    """A fresh context's one-shot render of a scene with a mesh of more than 800 triangles under the shader's rules plans
+    its probe from the camera rays' candidate lists (tiles with many candidate leaves are cut into slices of a sample
+    each): the same words as the oracle's, as with that plan switched off, and as with a garbage accumulator that is
+    discarded first (the slices' atomics then need the clear an overwriting launch would not)."""
+    import torch
+    cfg = rta.scenes.config3(width=112, height=64, spp=64, max_depth=4, mesh="bunny.off")
+    assert len(cfg.triangles) > 800
+    acc, ostats = orc.render(cfg.shapes, cfg.triangles, cfg.camera, oracle_params(orc, cfg))
+    ref = orc.resolve(acc, cfg.spp, cfg.semantics)
+    n_tiles = ((cfg.width + 15) // 16) * ((cfg.height + 15) // 16)
+    rt = rta.scenes.make_renderer(cfg)
+    st = rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, stats=True)
+    np.testing.assert_array_equal(rt.resolve(cfg.width, cfg.height).view(np.uint32), ref.view(np.uint32))
+    assert {k: st[k] for k in COUNTERS} == {k: ostats[k] for k in COUNTERS}
+    assert st["work_units"] > 2 * n_tiles                 # the probe's own slices on top of probe + rest
+    rt.close()
+    monkeypatch.setenv("RT_PROBE_PRIOR", "0")
+    rt = rta.scenes.make_renderer(cfg)
+    st0 = rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, stats=True)
+    np.testing.assert_array_equal(rt.resolve(cfg.width, cfg.height).view(np.uint32), ref.view(np.uint32))
+    assert st0["work_units"] < st["work_units"]
+    rt.close()
+    monkeypatch.delenv("RT_PROBE_PRIOR")
+    rt = rta.scenes.make_renderer(cfg)
+    buf = torch.full((cfg.height, cfg.width, 4), 987654321, dtype=torch.int32, device="cuda")
+    out = torch.empty(cfg.height, cfg.width, 4, dtype=torch.float32, device="cuda")
+    rt.bindAccum(buf.data_ptr(), cfg.width, cfg.height)
+    rt.discardAccum()
+    rt.renderResolved(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, out.data_ptr())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    rt.bindAccum(None, 0, 0)
+    rt.close()
+
+
 @pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5", "c5e"])
 def test_full_size_properties(rta, name, monkeypatch):
     """Configurations 2-5 (and 5 enclosed in its room of wall boxes) at their full sizes: properties that need no oracle run (counters, idempotence, linearity in

@@ -5,7 +5,7 @@ import numpy as np
 import ray_tracing_amd as rta
 from ray_tracing_amd import _abi
 name = sys.argv[1] if len(sys.argv) > 1 else "c2"
-cfg = rta.scenes.CONFIGS[name]()
+cfg = rta.scenes.CONFIGS[name](**({"mesh": os.environ["TL_MESH"]} if os.environ.get("TL_MESH") else {}))
 if len(sys.argv) > 2: cfg.spp = int(sys.argv[2])
 rt = rta.scenes.make_renderer(cfg)
 n_tiles = ((cfg.width + 15) // 16) * ((cfg.height + 15) // 16)
