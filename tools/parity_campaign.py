@@ -5,7 +5,7 @@ sample modes, both draw streams, the flags, cubes, dielectrics, debug and unknow
 sides, triangle colours, meshes from none to a few thousand triangles (staged in LDS or read from global memory),
 cameras inside and outside the scene, ragged frame sizes, depths 1 .. 9.
 
-    python tools/parity_campaign.py [--calls [--big]] [n_scenes] [first_seed]       # needs an MI355X; prints one line per failure
+    python tools/parity_campaign.py [--calls [--big] | --large-mesh] [n_scenes] [first_seed]       # needs an MI355X; prints one line per failure
 
 With --calls every scene (64 .. 100 samples per pixel) goes through every way of calling the renderer instead (see
 run_calls) and the accumulators are compared.
@@ -287,6 +287,49 @@ def run_calls(seed):
     return cfg, ostats, problems
 
 
+def run_large_mesh(seed):
+    """A one-shot render of a fresh context under the shader's rules, 64 .. 80 samples per pixel, of main.cpp's shapes
+    and 801 .. 4 968 faces of bunny.off seen from a random eye: the call whose probe is planned from the camera rays'
+    candidate lists (and whose rest runs by the plan made from that probe), then the same call again by the plan the
+    first one left, accumulators and counters against the oracle's."""
+    import torch
+    rng = np.random.default_rng(555000 + seed)
+    cfg = rta.scenes.config3(width=int(rng.integers(48, 129)), height=int(rng.integers(32, 81)), spp=int(rng.integers(64, 81)),
+                             max_depth=int(rng.integers(2, 6)), mesh="bunny.off")
+    keep = int(rng.integers(801, len(cfg.triangles) + 1))
+    start = int(rng.integers(0, len(cfg.triangles) - keep + 1))
+    cfg.triangles = cfg.triangles[start:start + keep]
+    eye = (float(rng.uniform(-3, 4)), float(rng.uniform(0.3, 3)), float(rng.uniform(2, 8)))
+    cam = host.Camera(cfg.width, cfg.height, float(rng.choice([0.7, 1.0, 1.6])), eye)
+    cfg.camera = cam.data.copy()
+    cfg.seed = int(rng.integers(1, 1 << 31))
+    w, h, spp, depth = cfg.width, cfg.height, cfg.spp, cfg.max_depth
+    p = orc.params(w, h, spp, depth, seed=cfg.seed, semantics=cfg.semantics, sample_mode=cfg.sample_mode, flags=cfg.flags,
+                   triangle_albedo=cfg.triangle_albedo, rng=cfg.rng, triangle_colors=cfg.triangle_colors)
+    acc, ostats = orc.render(cfg.shapes, cfg.triangles, cfg.camera, p)
+    ref = np.ascontiguousarray(acc).view(np.uint32).reshape(h, w, 4)[..., :3]
+    problems = []
+    buf = torch.zeros(h, w, 4, dtype=torch.int32, device="cuda")
+    rt = rta.scenes.make_renderer(cfg)
+    try:
+        rt.bindAccum(buf.data_ptr(), w, h)
+        for what in ("one-shot call of a fresh context", "the same call by the first one's plan"):
+            st = rt.render(w, h, spp, depth, cfg.seed, stats=True)
+            torch.cuda.synchronize()
+            got = buf.cpu().numpy().view(np.uint32)[..., :3]
+            if not np.array_equal(got, ref):
+                problems.append(f"{what}: {int((got != ref).sum())} of {ref.size} accumulator words")
+            bad = [k for k in COUNTERS if st[k] != ostats[k]]
+            if bad:
+                problems.append(f"{what}: counters {bad}")
+            buf.zero_()
+            torch.cuda.synchronize()
+        rt.bindAccum(None, 0, 0)
+    finally:
+        rt.close()
+    return cfg, ostats, problems
+
+
 BIG_FRAMES = False
 
 
@@ -298,13 +341,16 @@ def main():
     if "--big" in sys.argv:                                   # with --calls: frames of 100x60 .. 400x300 pixels
         sys.argv.remove("--big")
         BIG_FRAMES = True
+    large = "--large-mesh" in sys.argv
+    if large:
+        sys.argv.remove("--large-mesh")
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     t0 = time.time()
     failed = 0
     tot = dict(samples=0, segments=0, scenes=0, with_tris=0, with_boxes=0, sem0=0)
     for seed in range(first, first + n):
-        cfg, stats, problems = run_calls(seed) if calls else run_one(seed)
+        cfg, stats, problems = run_large_mesh(seed) if large else run_calls(seed) if calls else run_one(seed)
         tot["scenes"] += 1
         tot["samples"] += stats["samples"]; tot["segments"] += stats["segments"]
         tot["with_tris"] += 1 if len(cfg.triangles) else 0
@@ -316,7 +362,7 @@ def main():
                   f"flags {cfg.flags} rng {cfg.rng} shapes {len(cfg.shapes)} tris {len(cfg.triangles)}: " + "; ".join(problems), flush=True)
         if (seed - first + 1) % 25 == 0:
             print(f"... {seed - first + 1} scenes, {failed} failed, {time.time() - t0:.0f} s", flush=True)
-    print(("every way of calling the renderer: " if calls else "") + f"{tot['scenes']} random scenes (seeds {first} .. {first + n - 1}; {tot['sem0']} under the CPU tracer's rules, {tot['with_tris']} with "
+    print(("one-shot renders of a large mesh: " if large else "every way of calling the renderer: " if calls else "") + f"{tot['scenes']} random scenes (seeds {first} .. {first + n - 1}; {tot['sem0']} under the CPU tracer's rules, {tot['with_tris']} with "
           f"triangles, {tot['with_boxes']} with boxes), {tot['samples']} samples, {tot['segments']} segments: {failed} differ from the oracle")
     return 1 if failed else 0
 
