@@ -994,10 +994,8 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         // the view's second call in a row: count its steps (see rt_ctx::h_stats_copy)
         const bool measure = lists != nullptr && !stats && !timeline_host && ctx->view_streak >= 1u && !ctx->lists_measured && spp >= ctx->lists_min_spp;
         if (measure) {
-            if (!ctx->h_stats_copy) {
-                RT_HIP(ctx, hipHostMalloc(&ctx->h_stats_copy, sizeof(unsigned long long) * rtd::ST_COUNT));
-                RT_HIP(ctx, hipEventCreateWithFlags(&ctx->stats_copied, hipEventDisableTiming));
-            }
+            if (!ctx->h_stats_copy) RT_HIP(ctx, hipHostMalloc(&ctx->h_stats_copy, sizeof(unsigned long long) * rtd::ST_COUNT));
+            if (!ctx->stats_copied) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->stats_copied, hipEventDisableTiming));
             RT_HIP(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * rtd::ST_COUNT, ctx->stream));
         }
         const bool will_probe = !have_plan && !timeline_host && !ctx->env_no_probe && !ctx->env_no_tile_order && spp >= PROBE_MIN_SPP;
