@@ -1,4 +1,4 @@
-# A/B of prebuilt library variants (variants/*.so), two rounds, on the given configurations:
+# A/B of prebuilt library variants (variants/*.so), each measured twice, on the given configurations:
 #   bash tools/ab_variants.sh "c2 --steps 20;c5 --steps 10 --warmup 2" variant...
 IFS=';' read -ra CONFIGS <<< "$1"; shift
 cp ray_tracing_amd/librt_mi355x.so /tmp/librt_orig.so

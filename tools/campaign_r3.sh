@@ -1,4 +1,4 @@
-# The round's parity campaign inside one GPU call: random scenes with the camera rays' candidate lists in use at every
+# A parity campaign inside one GPU call: random scenes with the camera rays' candidate lists in use at every
 # sample count (RT_LISTS_MIN_SPP=1), then every way of calling the renderer.   bash tools/campaign_r3.sh
 set -o pipefail
 mkdir -p gpurun_out
