@@ -120,6 +120,7 @@ struct rt_ctx {
     uint32_t env_leaf = 0;               // RT_LEAF: triangles per tree leaf for every mesh (measurements); 0: chosen by mesh size
     uint32_t lists_min_spp = 32u;        // RT_LISTS_MIN_SPP: launches of fewer samples per pixel trace without the camera rays' lists (measurements, tests)
     uint32_t env_tree_levels = 0;        // RT_TREE_LEVELS: at most this many tree levels, 4 .. 8 (measurements); 0: as many as the mesh needs
+    uint32_t tree_top_max = rtd::TREE_TOP_MAX;   // RT_TREE_TOP: a tree gets levels until its top one has at most this many nodes (measurements, tests)
     float slice_share = 0.25f, slice_early = 0.5f;       // RT_SLICE_SHARE, RT_SLICE_EARLY (measurements)
     uint32_t slice_min_spp = 16u, slice_max = 16u;       // RT_SLICE_MIN_SPP, RT_SLICE_MAX
     uint32_t probe_spp = 0u;                             // RT_PROBE_SPP (0: the built-in PROBE_SPP)
@@ -378,7 +379,7 @@ static int plan_blob(rt_ctx* ctx, BlobPlan& B)
             L.node_n[l] = n;
             B.node_pad[l] = (n + rtd::TREE_FAN - 1u) / rtd::TREE_FAN * rtd::TREE_FAN;
             L.tree_levels = l + 1u;
-            if (l + 1u >= rtd::TREE_LEVELS && n <= rtd::TREE_TOP_MAX) break;
+            if (l + 1u >= rtd::TREE_LEVELS && n <= ctx->tree_top_max) break;
             n = (n + rtd::TREE_FAN - 1u) / rtd::TREE_FAN;
         }
         if (ctx->env_tree_levels) L.tree_levels = std::min(L.tree_levels, std::max(rtd::TREE_LEVELS, ctx->env_tree_levels));   // measurements
@@ -586,6 +587,7 @@ int rt_create(rt_ctx** out, const rt_config* cfg)
     ctx->env_no_probe = env_on("RT_NO_PROBE");
     if (const char* v = getenv("RT_LISTS_MIN_SPP")) { const int n = atoi(v); if (n >= 1) ctx->lists_min_spp = (uint32_t)n; }
     if (const char* v = getenv("RT_PROBE_PRIOR")) { const int n = atoi(v); if (n >= 0 && n <= 1000) ctx->probe_prior_weight = (uint32_t)n; }
+    if (const char* v = getenv("RT_TREE_TOP")) { const int n = atoi(v); if (n >= 1 && n <= 4096) ctx->tree_top_max = (uint32_t)n; }
     if (const char* v = getenv("RT_TREE_LEVELS")) { const int n = atoi(v); if (n >= (int)rtd::TREE_LEVELS && n <= (int)rtd::MAX_TREE_LEVELS) ctx->env_tree_levels = (uint32_t)n; }
     ctx->env_no_tile_lists = env_on("RT_NO_TILE_LISTS");
     if (const char* v = getenv("RT_SLICE_SHARE")) { const float f = (float)atof(v); if (f > 0.0f) ctx->slice_share = f; }
@@ -989,8 +991,10 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         }
         const uint32_t launched = plan_units;
         const uint32_t* lists = nullptr;
-        rc = ensure_lists(ctx, P, &lists);
-        if (rc) { if (d_timeline) (void)hipFree(d_timeline); return rc; }
+        if (spp >= ctx->lists_min_spp) {                   // a call of fewer samples would not use them: it does not make them either
+            rc = ensure_lists(ctx, P, &lists);
+            if (rc) { if (d_timeline) (void)hipFree(d_timeline); return rc; }
+        }
         // the view's second call in a row: count its steps (see rt_ctx::h_stats_copy)
         const bool measure = lists != nullptr && !stats && !timeline_host && ctx->view_streak >= 1u && !ctx->lists_measured && spp >= ctx->lists_min_spp;
         if (measure) {

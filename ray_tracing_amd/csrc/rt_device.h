@@ -53,18 +53,19 @@ namespace rtd {
 #define RT_TREE_FAN 8
 #endif
 #ifndef RT_TREE_TOP_MAX
-#define RT_TREE_TOP_MAX 32         // a tree gets levels until its top one has at most this many nodes (1: test builds, deep trees over small meshes)
+#define RT_TREE_TOP_MAX 128        // a tree gets levels until its top one has at most this many nodes (RT_TREE_TOP=n in the environment: another limit, 1 for deep trees over small meshes in tests)
 #endif
 #ifndef RT_MAX_TREE_LEVELS
 #define RT_MAX_TREE_LEVELS 8
 #endif
 // The walk handles the four levels 0 .. 3 with its queues and stacks.  A mesh whose level 3 would have more than
-// TREE_TOP_MAX nodes (some 65 000 triangles and more) gets further levels on top, up to MAX_TREE_LEVELS in all, until the
+// TREE_TOP_MAX nodes (some 260 000 triangles and more) gets further levels on top, up to MAX_TREE_LEVELS in all, until the
 // top one is that short: the wave descends through those together, depth first, and enters the level-3 nodes that any
 // of its rays can touch (SceneLayout::tree_levels; 4 for every smaller mesh, whose upper levels may hold a single node).
 // (Measured with a sheet of 20 000 triangles, ten level-3 nodes: a fifth level costs 8 % — scanning ten nodes is
-// cheaper than the shared stack —; with 199 712 triangles, 98 level-3 nodes, a fifth level makes no difference; with a
-// million triangles, 489 level-3 nodes, two more levels save a third of the frame.)
+// cheaper than the shared stack —; with 199 712 triangles, 98 level-3 nodes, a fifth level costs 2 % at 8 samples per
+// pixel and 7 % at 32; with a million triangles, 489 level-3 nodes, one more level (62 nodes on top) or two (8) save a
+// third of the frame, two 2-3 % more than one.)
 constexpr uint32_t TREE_LEAF = RT_TREE_LEAF, TREE_FAN = RT_TREE_FAN, TREE_LEVELS = 4, MAX_TREE_LEVELS = RT_MAX_TREE_LEVELS, TREE_TOP_MAX = RT_TREE_TOP_MAX;
 constexpr uint32_t SMALL_MESH_TRIS = 800u;
 constexpr uint32_t TREE_LEAF_SMALL = TREE_LEAF >= 2u ? TREE_LEAF / 2u : TREE_LEAF;

@@ -703,22 +703,28 @@ def test_mesh_larger_than_the_lds_stage(rta, orc):
 
 
 def test_mesh_of_two_hundred_thousand_triangles(rta, orc, monkeypatch):
-    """199 712 triangles: the tree has five levels (49 928 leaves, 6 241, 781, 98 and 13 nodes); the wave goes down
-    through the one above the walk's four together.  The exhaustive scan's result, and the same frame when the tree
-    is cut off at four levels (98 top nodes scanned one after the other)."""
+    """199 712 triangles: with a top level of at most 32 nodes the tree has five levels (49 928 leaves, 6 241, 781, 98
+    and 13 nodes) and the wave goes down through the one above the walk's four together; with a top level of one node,
+    six.  The exhaustive scan's result under both, and the same frame from the tree as shipped (four levels here: 98
+    top nodes scanned one after the other)."""
     cfg = rta.scenes.config3(width=48, height=27, spp=2, max_depth=4)
     cfg.triangles = _wavy_sheet(316)
     assert len(cfg.triangles) == 199712
+    monkeypatch.setenv("RT_TREE_TOP", "32")
     st = check_config(rta, orc, cfg)
     assert st["triangle_tests"] == st["segments"] * 199712
     frames = []
-    for levels in ("8", "4"):
-        monkeypatch.setenv("RT_TREE_LEVELS", levels)
+    for top in ("32", "1", None):
+        if top is None:
+            monkeypatch.delenv("RT_TREE_TOP")
+        else:
+            monkeypatch.setenv("RT_TREE_TOP", top)
         rt = rta.scenes.make_renderer(cfg)
         rt.render(cfg.width, cfg.height, 40, cfg.max_depth, cfg.seed)       # 40 samples: with the camera rays' lists
         frames.append(rt.resolve(cfg.width, cfg.height).view(np.uint32).copy())
         rt.close()
     np.testing.assert_array_equal(frames[0], frames[1])
+    np.testing.assert_array_equal(frames[0], frames[2])
 
 
 def test_mesh_scene_without_culling(rta, orc):

@@ -1,6 +1,6 @@
 """Frame time of the mesh scene with a rippled sheet of n x n x 2 triangles in place of the bunny, at 1080p, 8 samples
 per pixel: the tree with as many levels as the mesh needs against the tree cut off at four (RT_TREE_LEVELS=4), and the
-cost of the upload.   usage: python tools/big_mesh.py [n ...]      (default 100 316: 20 000 and 199 712 triangles)"""
+cost of the upload.   usage: python tools/big_mesh.py [n ...]      (default 100 316: 20 000 and 199 712 triangles; BIG_SPP=n: n samples per pixel)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -28,7 +28,7 @@ def sheet(n):
 
 
 for n in [int(a) for a in sys.argv[1:]] or [100, 316]:
-    cfg = rta.scenes.config3(spp=8)
+    cfg = rta.scenes.config3(spp=int(os.environ.get("BIG_SPP", "8")))
     cfg.triangles = sheet(n)
     for levels in ("8", "4"):
         os.environ["RT_TREE_LEVELS"] = levels
@@ -45,5 +45,5 @@ for n in [int(a) for a in sys.argv[1:]] or [100, 316]:
         rt.discardAccum()
         st = rt.render(cfg.width, cfg.height, cfg.spp, cfg.max_depth, cfg.seed, stats=True)
         rt.close()
-        print(f"{len(cfg.triangles):7d} triangles, at most {levels} tree levels: upload {upload * 1e3:7.1f} ms, frame {min(ms[2:]):7.2f} ms (1080p, 8 spp), "
+        print(f"{len(cfg.triangles):7d} triangles, at most {levels} tree levels: upload {upload * 1e3:7.1f} ms, frame {min(ms[2:]):7.2f} ms (1080p, {cfg.spp} spp; the first two frames {ms[0]:.2f} and {ms[1]:.2f}), "
               f"bound tests per segment {st['bound_tests_done'] / st['segments']:.1f}, triangle tests per segment {st['triangle_tests_done'] / st['segments']:.2f}", flush=True)
