@@ -118,7 +118,7 @@ struct rt_ctx {
     uint32_t group_waves = 4;           // waves per workgroup (RT_GROUP_WAVES: 1 .. 8, for measurements)
     bool env_no_tile_order = false, env_no_slices = false, env_mesh_in_lds = false, env_no_probe = false, env_no_tile_lists = false;
     uint32_t env_leaf = 0;               // RT_LEAF: triangles per tree leaf for every mesh (measurements); 0: chosen by mesh size
-    uint32_t lists_min_spp = 32u;        // RT_LISTS_MIN_SPP: launches of fewer samples per pixel trace without the camera rays' lists (measurements, tests)
+    uint32_t lists_min_spp = 0u;         // RT_LISTS_MIN_SPP: launches of fewer samples per pixel trace without the camera rays' lists (measurements, tests); 0: lists_min_spp_of()
     uint32_t env_tree_levels = 0;        // RT_TREE_LEVELS: at most this many tree levels, 4 .. 8 (measurements); 0: as many as the mesh needs
     uint32_t tree_top_max = rtd::TREE_TOP_MAX;   // RT_TREE_TOP: a tree gets levels until its top one has at most this many nodes (measurements, tests)
     float slice_share = 0.25f, slice_early = 0.5f;       // RT_SLICE_SHARE, RT_SLICE_EARLY (measurements)
@@ -825,9 +825,18 @@ static int make_plan(rt_ctx* ctx, uint32_t* cost, uint32_t* order, uint32_t n_ti
 }
 
 // Primary steps trade steps for work: a wave takes more, cheaper steps.  That pays while the machine is kept full; a
-// launch of a few samples per pixel is over before it is (measured on 512 x 512, 16 samples: 58 us without the
-// lists, 77 us with them), so such a launch traces without them.
-// (rt_ctx::lists_min_spp = 32)
+// launch of a few samples per pixel on a small frame is over before it is (measured on 512 x 512, 16 samples, four
+// spheres: 58 us without the lists, 77 us with them), so such a launch traces without them.  Where the waves outnumber
+// the machine's 8 192 slots at least twice, a scene of spheres profits from 16 samples per pixel on (1080p, four
+// spheres: 0.176 -> 0.167 ms; 8 samples: equal) and one of many spheres from 8 on (2048 x 2048, 65 spheres, 8 samples:
+// 1.04 -> 0.74 ms); a scene with boxes or a mesh from 32 on (the mesh scene at 8 and 16 samples: 2 % slower with them).
+static uint32_t lists_min_spp_of(const rt_ctx* ctx, const rtd::TraceParams& P)
+{
+    if (ctx->lists_min_spp) return ctx->lists_min_spp;
+    const bool spheres_only = P.scene.n_box == 0 && P.scene.n_tris == 0;
+    if (!spheres_only || 4u * P.tiles_x * P.tiles_y < 16384u) return 32u;
+    return P.scene.n_sph >= 8u ? 8u : 16u;
+}
 // ... and while a fair share of a wave's steps are primary steps: where paths are long (an enclosed scene: one camera
 // ray for fourteen segments) the steps' bookkeeping costs more than the few primary steps save (measured: 1.2 %).
 constexpr double LISTS_MIN_SHARE = 0.10;
@@ -909,7 +918,7 @@ static int trace_frame(rt_ctx* ctx, rtd::TraceParams P, uint32_t* accum, int mod
         }
         P.overwrite = 0u;                                  // the launch after the probe adds to what the probe stores
         RT_HIP(ctx, rtd::launch_trace((int)ctx->cfg.semantics, mode, ctx->stream, probe, ctx->d_blob, accum, ctx->d_stats, nullptr, nullptr,
-                                      probe_order, cost, probe_units, probe_spp >= ctx->lists_min_spp ? lists : nullptr));
+                                      probe_order, cost, probe_units, probe_spp >= lists_min_spp_of(ctx, P) ? lists : nullptr));
         P.first_sample += probe_spp; P.spp -= probe_spp;
         int rc = make_plan(ctx, cost, order, n_tiles, P.spp, plan_units);
         if (rc) return rc;
@@ -919,7 +928,7 @@ static int trace_frame(rt_ctx* ctx, rtd::TraceParams P, uint32_t* accum, int mod
         if (*plan_units != n_tiles) P.resolve_out = nullptr;
     }
     RT_HIP(ctx, rtd::launch_trace((int)ctx->cfg.semantics, mode, ctx->stream, P, ctx->d_blob, accum, ctx->d_stats, d_timeline, nullptr,
-                                  have_plan ? order : nullptr, cost, have_plan ? *plan_units : n_tiles, P.spp >= ctx->lists_min_spp ? lists : nullptr));
+                                  have_plan ? order : nullptr, cost, have_plan ? *plan_units : n_tiles, P.spp >= lists_min_spp_of(ctx, P) ? lists : nullptr));
     if (plan_after) return make_plan(ctx, cost, order, n_tiles, spp_all, plan_units);
     return RT_OK;
 }
@@ -991,12 +1000,12 @@ static int render_impl(rt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
         }
         const uint32_t launched = plan_units;
         const uint32_t* lists = nullptr;
-        if (spp >= ctx->lists_min_spp) {                   // a call of fewer samples would not use them: it does not make them either
+        if (spp >= lists_min_spp_of(ctx, P)) {              // a call of fewer samples would not use them: it does not make them either
             rc = ensure_lists(ctx, P, &lists);
             if (rc) { if (d_timeline) (void)hipFree(d_timeline); return rc; }
         }
         // the view's second call in a row: count its steps (see rt_ctx::h_stats_copy)
-        const bool measure = lists != nullptr && !stats && !timeline_host && ctx->view_streak >= 1u && !ctx->lists_measured && spp >= ctx->lists_min_spp;
+        const bool measure = lists != nullptr && !stats && !timeline_host && ctx->view_streak >= 1u && !ctx->lists_measured && spp >= lists_min_spp_of(ctx, P);
         if (measure) {
             if (!ctx->h_stats_copy) RT_HIP(ctx, hipHostMalloc(&ctx->h_stats_copy, sizeof(unsigned long long) * rtd::ST_COUNT));
             if (!ctx->stats_copied) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->stats_copied, hipEventDisableTiming));
