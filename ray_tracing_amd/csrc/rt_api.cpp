@@ -845,9 +845,9 @@ constexpr double LISTS_MIN_SHARE = 0.10;
 static int ensure_lists(rt_ctx* ctx, const rtd::TraceParams& P, const uint32_t** out)
 {
     *out = nullptr;
-    // (the masks of a list hold 128 spheres and 32 boxes: a scene beyond them has no lists)
+    // (the masks of a list hold 128 spheres — 960 when there is no mesh — and 32 boxes: a scene beyond them has no lists)
     if (ctx->env_no_tile_lists || P.rng_mode != 0 || (P.flags & RT_FLAG_LITERAL_GEOMETRY) != 0u ||
-        P.scene.n_sph > rtd::TLIST_MAX_SPHERES || P.scene.n_box > rtd::TLIST_MAX_BOXES ||
+        P.scene.n_sph > rtd::tlist_max_spheres(P.scene.n_tris != 0u) || P.scene.n_box > rtd::TLIST_MAX_BOXES ||
         (P.scene.n_sph < 2u && P.scene.n_box == 0 && P.scene.n_tris == 0)) return RT_OK;
     rt_ctx::ListKey key{};
     memcpy(key.cam, P.cam, sizeof key.cam);

@@ -129,7 +129,10 @@ enum { ST_SAMPLES = 0, ST_SEGMENTS, ST_DIFFUSE, ST_SPECULAR, ST_TERMINAL, ST_TRI
 #define RT_TLIST_SPH_WORDS 4
 #endif
 constexpr uint32_t TLIST_WORDS = 32u, TLIST_SPH_WORDS = RT_TLIST_SPH_WORDS, TLIST_LEAF0 = 2u + TLIST_SPH_WORDS, TLIST_MAX_LEAVES = TLIST_WORDS - TLIST_LEAF0,
-                   TLIST_NONE = 0xffffffffu, TLIST_MAX_SPHERES = 32u * TLIST_SPH_WORDS, TLIST_MAX_BOXES = 32u;
+                   TLIST_NONE = 0xffffffffu, TLIST_MAX_SPHERES = 32u * TLIST_SPH_WORDS, TLIST_MAX_BOXES = 32u,
+                   TLIST_MAX_SPHERES_NO_MESH = 32u * (TLIST_WORDS - 2u);
+// A scene without a mesh has no leaves to list: its sphere masks run on through the leaves' words (960 spheres).
+constexpr uint32_t tlist_max_spheres(bool has_mesh) { return has_mesh ? TLIST_MAX_SPHERES : TLIST_MAX_SPHERES_NO_MESH; }
 // A wave takes a primary step — only its lanes that are about to trace a camera ray take part, and they test the
 // tile's candidates instead of walking the scene — when all its live lanes are such, or at least this many.
 #ifndef RT_PSTEP_MIN

@@ -839,7 +839,7 @@ void trace_kernel(const TraceParams P,
     // candidates include every primitive whose test could accept such a ray, the closest hit is the same minimum
     // of (distance, index): the same words.  A step with fewer camera rays is an ordinary iteration for everyone.
     uint32_t pl_box = 0u, pl_n = TLIST_NONE, pl_sph0 = 0u;            // (the first 32 spheres' bits are kept at hand: most scenes have no more)
-    const uint32_t* pl_sph = nullptr;                                 // TLIST_SPH_WORDS words
+    const uint32_t* pl_sph = nullptr;                                 // TLIST_SPH_WORDS words, more for a scene of many spheres without a mesh
     const uint32_t* pl_leaves = nullptr;
     if (PSTEP && tile_lists) {
         const uint32_t wt = __builtin_amdgcn_readfirstlane((tile_y * 2u + (sub >> 1)) * (2u * P.tiles_x) + tile_x * 2u + (sub & 1u));
@@ -1643,7 +1643,7 @@ void tile_lists_kernel(const TraceParams P, const float4* __restrict__ blob, uin
     for (uint32_t w = 0; w < TLIST_SPH_WORDS; ++w) rec[2u + w] = 0u;
     if (gy_lo > gy_hi || gx_lo >= P.width) return;                 // no pixel: no wave reads this record
     const SceneLayout& L = P.scene;
-    if (L.n_sph > TLIST_MAX_SPHERES || L.n_box > TLIST_MAX_BOXES) return;   // beyond the masks: no lists for this scene
+    if (L.n_sph > tlist_max_spheres(L.n_tris != 0u) || L.n_box > TLIST_MAX_BOXES) return;   // beyond the masks: no lists for this scene
 
     // the tile's rectangle in pixel units, a little wider than its pixels; the grid as written lets the x offset
     // accumulate beyond the pixel (rayTracer.h:98-99): by less than grid_n / 2 pixels
@@ -1696,8 +1696,11 @@ void tile_lists_kernel(const TraceParams P, const float4* __restrict__ blob, uin
         }
         return in;
     };
-    uint32_t sph_mask[TLIST_SPH_WORDS], box_mask = 0u;
-    for (uint32_t w = 0; w < TLIST_SPH_WORDS; ++w) sph_mask[w] = 0u;
+    // (a scene without a mesh may have more spheres than TLIST_SPH_WORDS words hold: their bits go on into the words
+    // of the leaves it does not have)
+    const uint32_t sph_words = max(TLIST_SPH_WORDS, (L.n_sph + 31u) >> 5);
+    uint32_t box_mask = 0u;
+    for (uint32_t w = 0; w < sph_words; ++w) rec[2u + w] = 0u;
     for (uint32_t i = 0; i < L.n_sph; ++i) {
         const float4 sp = blob[L.sph_off + i];
         const double c[3] = { sp.x, sp.y, sp.z }, R = sqrt((double)sp.w);
@@ -1705,7 +1708,7 @@ void tile_lists_kernel(const TraceParams P, const float4* __restrict__ blob, uin
         const double far2 = d2 + f_min * f_min + R * R;
         // a sphere of radius zero or with a NaN in it: keep it a candidate (its test decides)
         const bool sane = R > 0.0 && far2 < 1e300;
-        if (!sane || reaches(c, R, nullptr, 0x1p-20 * far2 / R)) sph_mask[i >> 5] |= 1u << (i & 31u);
+        if (!sane || reaches(c, R, nullptr, 0x1p-20 * far2 / R)) rec[2u + (i >> 5)] |= 1u << (i & 31u);
     }
     for (uint32_t i = 0; i < L.n_box; ++i) {
         const float4 bc = blob[L.box_off + 3u * i], bh = blob[L.box_off + 3u * i + 2u];
@@ -1741,7 +1744,6 @@ void tile_lists_kernel(const TraceParams P, const float4* __restrict__ blob, uin
         }
     }
     rec[1] = box_mask;
-    for (uint32_t w = 0; w < TLIST_SPH_WORDS; ++w) rec[2u + w] = sph_mask[w];
     rec[0] = overflow ? TLIST_NONE : n_leaf;
 }
 

@@ -903,6 +903,25 @@ def test_many_hundred_shapes(rta, orc, sem):
         rta.scenes.make_renderer(cfg)
 
 
+@pytest.mark.parametrize("sem,n_sph", [(0, 129), (1, 500), (0, 960), (1, 961)])
+def test_candidate_lists_of_many_spheres(rta, orc, sem, n_sph, monkeypatch):
+    """A scene of spheres only has no leaves to list, so the sphere masks of a tile's candidate list run on through the
+    leaves' words: up to 960 spheres get primary steps (961 trace without), the same words as the oracle's either way."""
+    from ray_tracing_amd import host, _abi
+    rng = np.random.default_rng(77 + n_sph)
+    objs = [host.Circle((1, 60, -4), 20.0, host.Light((3, 3, 3)))]
+    for _ in range(n_sph - 1):
+        objs.append(host.Circle(tuple(float(x) for x in rng.uniform(-12, 12, 3) + (0, 0, -20)), float(rng.uniform(0.2, 1.2)),
+                                host.Lambertian(tuple(float(x) for x in rng.uniform(0.2, 1, 3))) if rng.random() < 0.7 else host.Metal((0.9, 0.9, 0.9))))
+    w, h = 72, 40
+    cfg = rta.scenes.SceneConfig("spheres", host.pack(objs, _abi.SHAPE_DTYPE), np.zeros(0, dtype=_abi.TRIANGLE_DTYPE),
+                                 host.Camera(w, h, 1.0, (1, 1, 6)).data.copy(), w, h, 3, 5, sem, seed=4)
+    monkeypatch.setenv("RT_LISTS_MIN_SPP", "1")
+    st = check_config(rta, orc, cfg)
+    assert (st["primary_steps"] > 0) == (n_sph <= 960)
+    assert st["sphere_tests_done"] < st["sphere_tests"] or n_sph > 960
+
+
 @pytest.mark.parametrize("seed", [241, 847, 949, 3, 22, 47])
 def test_campaign_scenes(rta, orc, seed):
     """Scenes of the randomised campaign (tools/parity_campaign.py: all modes, flags, materials and shape kinds mixed).
